@@ -1,0 +1,136 @@
+"""ctypes binding of libcrg_hip.so (include/crg_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, a Python exception
+is raised (the reference's ML process has no handler, modules/cremage/mp/mp.py:125, so clean
+exceptions - never aborts - are the contract).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcrg_hip.so")
+
+BF16, F32, F16 = 0, 1, 2
+PREC_BF16, PREC_BF16X3 = 0, 1
+EPI_NONE, EPI_SILU, EPI_GEGLU = 0, 1, 2
+BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
+PACK_LINEAR, PACK_CONV, PACK_GEGLU = 0, 1, 2
+K_FAMILIES = 8
+FAMILY_NAMES = ["gemm", "conv", "attention", "groupnorm", "layernorm", "elementwise", "conv_small", "softmax"]
+
+c_void_p, c_int, c_int64, c_float, c_size_t = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("a", c_void_p), ("lda", c_int64), ("a_bstride", c_int64),
+        ("w", c_void_p), ("ldw", c_int64), ("w_bstride", c_int64),
+        ("w_lo", c_void_p),
+        ("bias", c_void_p), ("bias_mode", c_int),
+        ("residual", c_void_p), ("ldr", c_int64), ("r_bstride", c_int64),
+        ("y", c_void_p), ("ldy", c_int64), ("y_bstride", c_int64),
+        ("M", c_int), ("N", c_int), ("K", c_int), ("batch", c_int),
+        ("epilogue", c_int),
+        ("a_dtype", c_int), ("y_dtype", c_int), ("prec", c_int),
+        ("a_is_weight", c_int),
+        ("a_lo", c_void_p),
+    ]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("x", c_void_p), ("x2", c_void_p), ("C1", c_int), ("C2", c_int),
+        ("w", c_void_p), ("w_lo", c_void_p),
+        ("bias", c_void_p), ("cvec", c_void_p),
+        ("residual", c_void_p),
+        ("y", c_void_p),
+        ("N", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int), ("Ho", c_int), ("Wo", c_int),
+        ("ksize", c_int), ("stride", c_int), ("pad_t", c_int), ("pad_l", c_int),
+        ("upsample2x", c_int),
+        ("x_dtype", c_int), ("y_dtype", c_int), ("prec", c_int),
+    ]
+
+
+class Profile(C.Structure):
+    _fields_ = [("ms", C.c_double * K_FAMILIES), ("flops", C.c_double * K_FAMILIES), ("bytes", C.c_double * K_FAMILIES),
+                ("launches", C.c_int64 * K_FAMILIES)]
+
+
+# name -> (restype, argtypes); every symbol include/crg_hip.h declares
+SIGNATURES = {
+    "crg_version": (c_int, []),
+    "crg_ctx_create": (c_int, [c_int, C.POINTER(c_void_p)]),
+    "crg_ctx_destroy": (None, [c_void_p]),
+    "crg_last_error": (C.c_char_p, [c_void_p]),
+    "crg_ctx_reserve": (c_int, [c_void_p, c_size_t]),
+    "crg_profile_begin": (c_int, [c_void_p]),
+    "crg_profile_end": (c_int, [c_void_p, c_void_p, C.POINTER(Profile)]),
+    "crg_groupnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                              c_int, c_float, c_int, c_int]),
+    "crg_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int]),
+    "crg_gemm": (c_int, [c_void_p, c_void_p, C.POINTER(GemmArgs)]),
+    "crg_conv2d": (c_int, [c_void_p, c_void_p, C.POINTER(ConvArgs)]),
+    "crg_pack_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "crg_pack_geglu_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "crg_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                              c_int, c_int, c_int, c_int, c_int, c_float, c_int]),
+    "crg_softmax_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_float, c_int]),
+    "crg_conv_small": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_int]),
+    "crg_timestep_embedding": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "crg_silu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int]),
+    "crg_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "crg_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "crg_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_int]),
+    "crg_affine_cast": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int,
+                                c_int]),
+}
+
+
+class CrgError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CrgError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(cremage_amd has no CPU or PyTorch fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.crg_version() != 100:
+        raise CrgError(f"libcrg_hip.so version {lib.crg_version()} does not match the binding (100)")
+    _lib = lib
+    return lib
+
+
+_ctxs = {}
+
+
+def ctx(device_index: int):
+    """One context per device (include/crg_hip.h: not re-entrant, single-threaded caller)."""
+    h = _ctxs.get(device_index)
+    if h is None:
+        lib = load()
+        out = c_void_p()
+        rc = lib.crg_ctx_create(device_index, C.byref(out))
+        if rc != 0:
+            raise CrgError(f"crg_ctx_create(device={device_index}) failed with {rc}: no usable HIP device")
+        h = out
+        _ctxs[device_index] = h
+    return h
+
+
+def check(rc: int, h, what: str):
+    if rc != 0:
+        msg = load().crg_last_error(h)
+        raise CrgError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,63 @@
+"""In-tree build of libcrg_hip.so (hipcc, --offload-arch=gfx950 only).
+
+The built library lives next to this file (cremage_amd/libcrg_hip.so): it is git-ignored but
+travels to the GPU box with the source snapshot.  Objects are cached under cremage_amd/csrc/_obj
+keyed on source mtime so that a rebuild only recompiles what changed.
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libcrg_hip.so")
+SOURCES = ["crg_api.hip", "gemm_conv.hip", "norms.hip", "attention.hip", "small_ops.hip"]
+HEADERS = [os.path.join(CSRC, "crg_common.h"), os.path.join(HERE, "..", "include", "crg_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def _compile(src):
+    s = os.path.join(CSRC, src)
+    o = os.path.join(OBJ, src.replace(".hip", ".o"))
+    if not (_newer(s, o) or any(_newer(h, o) for h in HEADERS)):
+        return o, False
+    cmd = [_hipcc()] + FLAGS + ["-c", s, "-o", o]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+    return o, True
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    with cf.ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+        res = list(ex.map(_compile, SOURCES))
+    objs = [o for o, _ in res]
+    if any(ch for _, ch in res) or not os.path.exists(LIB):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        if verbose:
+            print(f"[cremage_amd.build] linked {LIB}", file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,254 @@
+// Flash-style attention for gfx950: O = softmax(Q K^T * scale) V, bf16 in/out, fp32 softmax and
+// accumulation, never materialising the Nq x Nk score matrix (the reference's original/sliced paths
+// do: attention.py:646-658, 415-424).
+//
+// One block = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries.  Per 64-key
+// tile, all on v_mfma_f32_32x32x16_bf16:
+//   S^T[key][query] = K_tile (A operand, from LDS) x Q^T (B operand, registers for the whole kernel)
+//     -> the query sits on the LANE and the keys in the 16 accumulator registers, so the row max /
+//        row sum are register reductions plus ONE cross-half shuffle;
+//   O^T[d][query]  += V^T_tile (A operand, from LDS) x P^T (B operand = the S^T accumulator itself,
+//        converted pairwise to bf16: guide §3 "An accumulator tile as the next MFMA's operand"; the
+//        k order inside a 16-key step is row 16s + 8(j>>2) + 4h + (j&3), so V^T is read as two 8-byte
+//        pieces per step at key offsets 16s+4h and 16s+8+4h).
+// V arrives TRANSPOSED from HBM ([channel][key]; emitted by the V projection GEMM with swapped
+// operands), so no transposing LDS read is needed.  Head dims are padded to KS*16 (QK^T) and NV*32
+// (PV) with zeros: d_head 40 -> 48/64, 80 -> 80/96, 160 -> 160/160, 64 -> 64/64.
+//
+// LDS: K tile [64][KS*16] with rows padded to 16*(2KS+1) bytes, V^T tile [NV*32][64] with rows padded
+// to 136 bytes: both fragment read patterns are bank-conflict free (guide §2 bank rules).
+#include "crg_common.h"
+
+namespace {
+
+struct AttnP {
+  const bf16* q; const bf16* k; const bf16* vt; bf16* o;
+  long ldq, ldk, ldvt, ldo;
+  int B, H, Nq, Nk, Dh;
+  float scale_log2;
+};
+
+constexpr int VROW = 136;  // bytes per V^T LDS row (64 keys * 2 B + 8 pad)
+
+template <int KS, int NV>
+__global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
+  constexpr int KROW = KS * 32 + 16;  // bytes per K LDS row
+  constexpr int KCH = 2 * KS;         // 16-byte chunks per K row
+  constexpr int KLOADS = (64 * KCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) char Ks[64 * KROW];
+  __shared__ __attribute__((aligned(16))) char Vs[NV * 32 * VROW];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+
+  const bf16* Q = p.q + (long)b * p.Nq * p.ldq + (long)h * p.Dh;
+  const bf16* K = p.k + (long)b * p.Nk * p.ldk + (long)h * p.Dh;
+  const bf16* VT = p.vt + ((long)b * p.H + h) * p.Dh * p.ldvt;
+  bf16* O = p.o + (long)b * p.Nq * p.ldo + (long)h * p.Dh;
+
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  // ---- Q fragments (B operand): lane (r, hh) holds Q[q0 + r][16 s + 8 hh + j] ----
+  bf16x8 qf[KS];
+  {
+    const int query = q0 + r;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int d0 = 16 * s + 8 * hh;
+      qf[s] = (query < p.Nq && d0 < p.Dh) ? *reinterpret_cast<const bf16x8*>(Q + (long)query * p.ldq + d0) : zero8;
+    }
+  }
+
+  f32x16 oacc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  bf16x8 kreg[KLOADS], vreg[NV];
+  auto prefetch = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < KLOADS; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx / KCH, c = idx - row * KCH;
+      const int key = tile * 64 + row;
+      kreg[i] = (idx < 64 * KCH && key < p.Nk && c * 8 < p.Dh) ? *reinterpret_cast<const bf16x8*>(K + (long)key * p.ldk + c * 8) : zero8;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx >> 3, c = idx & 7;
+      const int key0 = tile * 64 + c * 8;
+      bf16x8 v = zero8;
+      if (row < p.Dh && key0 < p.Nk) {
+        v = *reinterpret_cast<const bf16x8*>(VT + (long)row * p.ldvt + key0);
+        if (key0 + 8 > p.Nk) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (key0 + e >= p.Nk) v[e] = (bf16)0.f;
+        }
+      }
+      vreg[i] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < KLOADS; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx / KCH, c = idx - row * KCH;
+      if (idx < 64 * KCH) *reinterpret_cast<bf16x8*>(Ks + row * KROW + c * 16) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx >> 3, c = idx & 7;
+      const uint2* src = reinterpret_cast<const uint2*>(&vreg[i]);
+      uint2* dst = reinterpret_cast<uint2*>(Vs + row * VROW + c * 16);  // rows are only 8-byte aligned
+      dst[0] = src[0];
+      dst[1] = src[1];
+    }
+  };
+
+  const int ntiles = (p.Nk + 63) / 64;
+  prefetch(0);
+  for (int tile = 0; tile < ntiles; ++tile) {
+    __syncthreads();  // previous tile's LDS reads are done
+    commit();
+    __syncthreads();
+    if (tile + 1 < ntiles) prefetch(tile + 1);
+
+    // ---- S^T = K Q^T ----
+    f32x16 st[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[kb][e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kb * 32 + r) * KROW + (2 * s + hh) * 16);
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kb], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (base 2) ----
+    const bool last = (tile + 1 == ntiles) && (p.Nk & 63);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float s = st[kb][e] * p.scale_log2;
+        if (last) {
+          const int key = tile * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (key >= p.Nk) s = -INFINITY;
+        }
+        st[kb][e] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pe = __builtin_amdgcn_exp2f(st[kb][e] - m_new);
+        st[kb][e] = pe;
+        rs += pe;
+      }
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+    // ---- P^T fragments straight from the accumulator registers ----
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[kb][s2][j] = (bf16)st[kb][8 * s2 + j];
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int dv = 0; dv < NV; ++dv) {
+      const char* vrow = Vs + (dv * 32 + r) * VROW;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int keyoff = kb * 32 + 16 * s2 + 4 * hh;
+          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + keyoff * 2);
+          const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + (keyoff + 8) * 2);
+          const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          oacc[dv] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], oacc[dv], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- normalise and store: lane = query, registers = channels (4 consecutive per group) ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  const int query = q0 + r;
+  if (query < p.Nq) {
+#pragma unroll
+    for (int dv = 0; dv < NV; ++dv)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dv * 32 + 8 * g + 4 * hh;
+        if (d < p.Dh) {
+          bf16x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = (bf16)(oacc[dv][4 * g + e] * inv);
+          *reinterpret_cast<bf16x4*>(O + (long)query * p.ldo + d) = o4;
+        }
+      }
+  }
+}
+
+template <int KS, int NV>
+int launch_attn(crg_ctx* ctx, hipStream_t st, const AttnP& p) {
+  dim3 grid((p.Nq + 127) / 128, p.B * p.H);
+  hipLaunchKernelGGL((attn_kernel<KS, NV>), grid, dim3(256), 0, st, p);
+  CRG_CHECK_LAUNCH(ctx, "attention");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int crg_attention(crg_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                             const void* vt, int64_t ldvt, void* o, int64_t ldo, int B, int H, int Nq, int Nk, int Dh,
+                             float scale, int dtype) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, dtype == CRG_BF16, "attention: only bf16 is implemented (dtype %d)", dtype);
+  CRG_REQUIRE(ctx, B > 0 && H > 0 && Nq > 0 && Nk > 0, "attention: empty problem B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
+  CRG_REQUIRE(ctx, Dh % 8 == 0 && Dh >= 8 && Dh <= 160, "attention: head dim %d unsupported (multiple of 8, <= 160)", Dh);
+  CRG_REQUIRE(ctx, ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attention: leading dimensions must keep 16-byte alignment");
+  CRG_REQUIRE(ctx, ldvt >= ((Nk + 7) / 8) * 8, "attention: ldvt=%ld must cover Nk=%d rounded up to 8", (long)ldvt, Nk);
+  CRG_REQUIRE(ctx, (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) == 0 && ((uintptr_t)o & 7) == 0, "attention: pointers must be 16-byte aligned");
+  AttnP p{(const bf16*)q, (const bf16*)k, (const bf16*)vt, (bf16*)o, (long)ldq, (long)ldk, (long)ldvt, (long)ldo, B, H, Nq, Nk, Dh,
+          scale * 1.4426950408889634f};
+  hipStream_t st = (hipStream_t)stream;
+  const double flops = 4.0 * B * H * (double)Nq * Nk * Dh;
+  const double bytes = 2.0 * B * H * Dh * (2.0 * Nq + 2.0 * Nk);
+  crg_prof_scope ps(ctx, st, CRG_K_ATTN, flops, bytes);
+  const int ks = (Dh + 15) / 16;
+  switch (ks) {
+    case 1: return launch_attn<1, 1>(ctx, st, p);
+    case 2: return launch_attn<2, 1>(ctx, st, p);
+    case 3: return launch_attn<3, 2>(ctx, st, p);
+    case 4: return launch_attn<4, 2>(ctx, st, p);
+    case 5: return launch_attn<5, 3>(ctx, st, p);
+    case 6: return launch_attn<6, 3>(ctx, st, p);
+    case 7: return launch_attn<7, 4>(ctx, st, p);
+    case 8: return launch_attn<8, 4>(ctx, st, p);
+    case 9: return launch_attn<9, 5>(ctx, st, p);
+    case 10: return launch_attn<10, 5>(ctx, st, p);
+  }
+  return crg_fail(ctx, -22, "attention: head dim %d unsupported", Dh);
+}

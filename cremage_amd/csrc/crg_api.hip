@@ -1,0 +1,185 @@
+// Context, error reporting, scratch, per-launch event timing and weight packing.
+#include "crg_common.h"
+
+int crg_fail(crg_ctx* ctx, int code, const char* fmt, ...) {
+  if (ctx) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    ctx->err = buf;
+  }
+  return code;
+}
+
+void* crg_scratch(crg_ctx* ctx, size_t bytes) {
+  if (ctx->scratch_bytes >= bytes) return ctx->scratch;
+  if (ctx->scratch) {
+    (void)hipDeviceSynchronize();
+    (void)hipFree(ctx->scratch);
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+  }
+  size_t want = bytes < (size_t(8) << 20) ? (size_t(8) << 20) : bytes;
+  if (hipMalloc(&ctx->scratch, want) != hipSuccess) {
+    ctx->scratch = nullptr;
+    return nullptr;
+  }
+  ctx->scratch_bytes = want;
+  return ctx->scratch;
+}
+
+crg_prof_scope::crg_prof_scope(crg_ctx* c, hipStream_t s, int family, double flops, double bytes) : ctx(c), st(s) {
+  if (!c || !c->profiling) return;
+  crg_prof_rec r;
+  r.family = family;
+  r.flops = flops;
+  r.bytes = bytes;
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+  (void)hipEventRecord(r.e0, s);
+  c->recs.push_back(r);
+  idx = (int)c->recs.size() - 1;
+}
+crg_prof_scope::~crg_prof_scope() {
+  if (idx >= 0) (void)hipEventRecord(ctx->recs[idx].e1, st);
+}
+
+extern "C" int crg_version(void) { return CRG_VERSION; }
+
+extern "C" int crg_ctx_create(int device, crg_ctx** out) {
+  if (!out) return -22;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return -19;  // ENODEV
+  if (hipSetDevice(device) != hipSuccess) return -19;
+  crg_ctx* c = new (std::nothrow) crg_ctx();
+  if (!c) return -12;
+  c->device = device;
+  *out = c;
+  return 0;
+}
+
+extern "C" void crg_ctx_destroy(crg_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  for (auto& r : ctx->recs) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  delete ctx;
+}
+
+extern "C" const char* crg_last_error(crg_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int crg_ctx_reserve(crg_ctx* ctx, size_t bytes) {
+  if (!ctx) return -22;
+  return crg_scratch(ctx, bytes) ? 0 : crg_fail(ctx, -12, "cannot reserve %zu bytes of scratch", bytes);
+}
+
+extern "C" int crg_profile_begin(crg_ctx* ctx) {
+  if (!ctx) return -22;
+  for (auto& r : ctx->recs) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  ctx->recs.clear();
+  ctx->profiling = true;
+  return 0;
+}
+
+extern "C" int crg_profile_end(crg_ctx* ctx, void* stream, crg_profile* out) {
+  if (!ctx || !out) return -22;
+  ctx->profiling = false;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return crg_fail(ctx, -5, "profile_end: stream sync failed");
+  for (int i = 0; i < CRG_K_FAMILIES; ++i) {
+    out->ms[i] = out->flops[i] = out->bytes[i] = 0.0;
+    out->launches[i] = 0;
+  }
+  for (auto& r : ctx->recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess && r.family >= 0 && r.family < CRG_K_FAMILIES) {
+      out->ms[r.family] += ms;
+      out->flops[r.family] += r.flops;
+      out->bytes[r.family] += r.bytes;
+      out->launches[r.family] += 1;
+    }
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  ctx->recs.clear();
+  return 0;
+}
+
+// ---- weight packing ------------------------------------------------------------------------------
+namespace {
+
+template <typename ST>
+__global__ void pack_kernel(const ST* __restrict__ src, bf16* __restrict__ hi, bf16* __restrict__ lo, int kind, int n_out,
+                            int n_in, int ks, long total) {
+  // destination element index d -> (row o, col k); CONV: k = tap * n_in + ci <- src[o][ci][tap]
+  for (long d = (long)blockIdx.x * blockDim.x + threadIdx.x; d < total; d += (long)gridDim.x * blockDim.x) {
+    const int kk = ks * ks * n_in;
+    const int o = (int)(d / kk);
+    const int k = (int)(d - (long)o * kk);
+    long s;
+    if (kind == CRG_PACK_CONV) {
+      const int tap = k / n_in, ci = k - tap * n_in;
+      s = ((long)o * n_in + ci) * (ks * ks) + tap;
+    } else if (kind == CRG_PACK_GEGLU) {
+      // packed row o: group q = o/32, r = o%32 -> source row j + half*F, j = q*16 + r%16, half = r/16
+      const int F = n_out / 2;
+      const int q = o >> 5, r = o & 31;
+      const int j = q * 16 + (r & 15);
+      const int srow = j + (r >> 4) * F;
+      s = (long)srow * n_in + k;
+    } else {
+      s = d;
+    }
+    const float f = (float)src[s];
+    const bf16 h = (bf16)f;
+    hi[d] = h;
+    if (lo) lo[d] = (bf16)(f - (float)h);
+  }
+}
+
+__global__ void pack_geglu_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int n2) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n2) return;
+  const int F = n2 / 2;
+  const int q = o >> 5, r = o & 31;
+  dst[o] = src[q * 16 + (r & 15) + (r >> 4) * F];
+}
+
+}  // namespace
+
+extern "C" int crg_pack_weight(crg_ctx* ctx, void* stream, const void* src, int src_dtype, int kind, int n_out, int n_in,
+                               int ksize, void* dst_hi, void* dst_lo) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, src && dst_hi && n_out > 0 && n_in > 0, "pack_weight: bad arguments");
+  if (kind != CRG_PACK_CONV) ksize = 1;
+  CRG_REQUIRE(ctx, ksize == 1 || ksize == 3, "pack_weight: ksize %d unsupported", ksize);
+  if (kind == CRG_PACK_GEGLU) CRG_REQUIRE(ctx, n_out % 32 == 0, "pack_weight: GEGLU needs n_out %% 32 == 0, got %d", n_out);
+  const long total = (long)n_out * n_in * ksize * ksize;
+  const int block = 256;
+  const int grid = (int)((total + block - 1) / block < 4096 ? (total + block - 1) / block : 4096);
+  hipStream_t st = (hipStream_t)stream;
+  if (src_dtype == CRG_F32)
+    hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(block), 0, st, (const float*)src, (bf16*)dst_hi, (bf16*)dst_lo, kind, n_out, n_in, ksize, total);
+  else if (src_dtype == CRG_BF16)
+    hipLaunchKernelGGL(pack_kernel<bf16>, dim3(grid), dim3(block), 0, st, (const bf16*)src, (bf16*)dst_hi, (bf16*)dst_lo, kind, n_out, n_in, ksize, total);
+  else if (src_dtype == CRG_F16)
+    hipLaunchKernelGGL(pack_kernel<_Float16>, dim3(grid), dim3(block), 0, st, (const _Float16*)src, (bf16*)dst_hi, (bf16*)dst_lo, kind, n_out, n_in, ksize, total);
+  else
+    return crg_fail(ctx, -22, "pack_weight: unsupported source dtype %d", src_dtype);
+  CRG_CHECK_LAUNCH(ctx, "pack_weight");
+  return 0;
+}
+
+extern "C" int crg_pack_geglu_bias(crg_ctx* ctx, void* stream, const float* src, int n_out2, float* dst) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, src && dst && n_out2 > 0 && n_out2 % 32 == 0, "pack_geglu_bias: n_out2 %% 32 != 0");
+  hipLaunchKernelGGL(pack_geglu_bias_kernel, dim3((n_out2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, n_out2);
+  CRG_CHECK_LAUNCH(ctx, "pack_geglu_bias");
+  return 0;
+}

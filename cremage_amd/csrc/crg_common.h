@@ -1,0 +1,96 @@
+// Shared device/host helpers for libcrg_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/crg_hip.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CRG_WAVE 64
+
+// ---- context ------------------------------------------------------------------------------
+struct crg_prof_rec {
+  hipEvent_t e0, e1;
+  int family;
+  double flops, bytes;
+};
+
+struct crg_ctx {
+  int device = 0;
+  std::string err;
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  bool profiling = false;
+  std::vector<crg_prof_rec> recs;
+  std::vector<hipEvent_t> event_pool;
+};
+
+int crg_fail(crg_ctx* ctx, int code, const char* fmt, ...);
+// scratch of at least `bytes` (grows with hipMalloc when too small: NOT capture-safe, so callers
+// running under graph capture must crg_ctx_reserve first)
+void* crg_scratch(crg_ctx* ctx, size_t bytes);
+
+// RAII bracket used by every launcher: records events when profiling is on.
+struct crg_prof_scope {
+  crg_ctx* ctx;
+  hipStream_t st;
+  int idx = -1;
+  crg_prof_scope(crg_ctx* c, hipStream_t s, int family, double flops, double bytes);
+  ~crg_prof_scope();
+};
+
+#define CRG_CHECK_LAUNCH(ctx, what)                                                    \
+  do {                                                                                 \
+    hipError_t e_ = hipGetLastError();                                                 \
+    if (e_ != hipSuccess) return crg_fail(ctx, -5, "%s: launch failed: %s", what, hipGetErrorString(e_)); \
+  } while (0)
+
+#define CRG_REQUIRE(ctx, cond, ...)                         \
+  do {                                                      \
+    if (!(cond)) return crg_fail(ctx, -22, __VA_ARGS__);    \
+  } while (0)
+
+static inline size_t crg_dtype_size(int dt) { return dt == CRG_F32 ? 4 : 2; }
+
+// ---- device helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float crg_silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float crg_gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <typename T>
+struct crg_vec8;  // 8 consecutive elements of T, loaded/stored as one (bf16) or two (f32) 16-byte accesses
+template <>
+struct crg_vec8<bf16> {
+  bf16x8 v;
+  __device__ __forceinline__ void load(const bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ void store(bf16* p) const { *reinterpret_cast<bf16x8*>(p) = v; }
+  __device__ __forceinline__ void zero() { v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  __device__ __forceinline__ void set(int i, float f) { v[i] = (bf16)f; }
+};
+template <>
+struct crg_vec8<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = *reinterpret_cast<const f32x4*>(p);
+    b = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  __device__ __forceinline__ void store(float* p) const {
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+  }
+  __device__ __forceinline__ void zero() { a = f32x4{0, 0, 0, 0}; b = f32x4{0, 0, 0, 0}; }
+  __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b[i - 4]; }
+  __device__ __forceinline__ void set(int i, float f) { if (i < 4) a[i] = f; else b[i - 4] = f; }
+};

@@ -1,0 +1,441 @@
+// MFMA GEMM / implicit-GEMM conv2d for gfx950.
+//
+//   Y[m][n] = epilogue( sum_k X[m][k] * W[n][k] )      (both operands K-contiguous)
+//
+// Block tile 128(m) x 32*WNT(n) x 64(k), 256 threads = 4 waves as 2(m) x 2(n); each wave owns
+// 64(m) x 16*WNT(n) as 4 x WNT accumulators of v_mfma_f32_16x16x32_bf16.  The MFMA is issued with
+// the WEIGHT tile as the A operand and the ACTIVATION tile as the B operand, so that D rows = n:
+// a lane then holds 4 CONSECUTIVE output channels of one output row, and the epilogue (bias,
+// timestep-embedding vector, residual, SiLU/GEGLU) runs on 4-wide vectors with 8/16-byte stores.
+//
+// Staging: global -> registers -> LDS (ds_write_b128), double-buffered LDS, one barrier per k-tile;
+// the loads of k-tile t+1 are issued before the MFMAs of tile t and written after them (guide
+// §6 G15 "async-STAGE split").  LDS rows are 128 B with the 16-B chunk index XOR-swizzled by
+// (row & 7) so that the ds_read_b128 fragment reads (16 rows x same chunk) are conflict-free.
+//
+// The conv variant only changes the activation loader: row m -> (image, ho, wo), k -> (tap, channel)
+// with zero fill outside the (optionally nearest-2x-upsampled) image and a second input pointer
+// for the UNet skip concat.  BF16X3 (NSPLIT=2) stages hi and lo bf16 planes of both operands and
+// issues hi*hi + hi*lo + lo*hi.
+#include "crg_common.h"
+
+namespace {
+
+struct GemmP {
+  const void* a; const void* a_lo; long lda, a_bs;
+  const bf16* w; const bf16* w_lo; long ldw, w_bs;
+  const float* bias; int bias_mode;
+  const void* res; long ldr, r_bs;
+  void* y; long ldy, y_bs;
+  int M, N, K, epi;
+  const float* cvec; int cvec_rows;  // cvec[(m / cvec_rows) * N + n]
+  int a_is_weight;
+  // conv geometry
+  const void* x2; int C1, C2, Ctot, H, W, Ho, Wo, ks, stride, pad_t, pad_l, up;
+  int tiles_n, tiles_m;
+};
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+__device__ __forceinline__ bf16x8 split_hi(const crg_vec8<float>& v, bf16x8& lo) {
+  bf16x8 hi;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float f = v.get(i);
+    bf16 h = (bf16)f;
+    hi[i] = h;
+    lo[i] = (bf16)(f - (float)h);
+  }
+  return hi;
+}
+
+template <int WNT, int NSPLIT, typename AT, typename YT, bool CONV>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+  constexpr int BN = 32 * WNT;
+  constexpr int XS_BYTES = BM * 128;
+  constexpr int WS_BYTES = BN * 128;
+  constexpr int STAGE_BYTES = NSPLIT * (XS_BYTES + WS_BYTES);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile order: blocks b, b+8, ... share an XCD (L2); give each XCD a contiguous run of
+  // tiles ordered n-fastest so neighbouring blocks reuse the same activation rows and the whole
+  // weight panel stays L2-resident (guide T1, bijective form).
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % p.tiles_n;
+  const int tile_m = bid / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int bz = blockIdx.y;
+
+  const AT* A = reinterpret_cast<const AT*>(p.a) + (long)bz * p.a_bs;
+  const bf16* A_lo = p.a_lo ? reinterpret_cast<const bf16*>(p.a_lo) + (long)bz * p.a_bs : nullptr;
+  const bf16* Wp = p.w + (long)bz * p.w_bs;
+  const bf16* Wlo = (NSPLIT == 2) ? p.w_lo + (long)bz * p.w_bs : nullptr;
+
+  const int cc = t & 7;   // 16-byte chunk column inside the 64-wide k-tile
+  const int r0 = t >> 3;  // 0..31
+
+  // ---- per-thread row descriptors (fixed for the whole K loop) ----
+  long xrow_off[4];   // linear: element offset of row start; conv: image index
+  int xh[4], xw[4];   // conv: top-left input coordinate (virtual = after upsample)
+  bool xok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    xok[i] = m < p.M;
+    if (CONV) {
+      const int hw = p.Ho * p.Wo;
+      const int img = m / hw;
+      const int rem = m - img * hw;
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      xrow_off[i] = img;
+      xh[i] = ho * p.stride - p.pad_t;
+      xw[i] = wo * p.stride - p.pad_l;
+    } else {
+      xrow_off[i] = (long)m * p.lda;
+      xh[i] = xw[i] = 0;
+    }
+  }
+  bool wok[WNT];
+  long wrow_off[WNT];
+#pragma unroll
+  for (int i = 0; i < WNT; ++i) {
+    const int n = n0 + r0 + 32 * i;
+    wok[i] = n < p.N;
+    wrow_off[i] = (long)n * p.ldw;
+  }
+
+  crg_vec8<AT> xr[4];
+  bf16x8 xr_lo[4];  // only when A is a pre-split weight (a_is_weight)
+  bf16x8 wr[WNT], wr_lo[WNT];
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  auto load_tile = [&](int kt) {
+    const int kc = kt * BK + cc * 8;
+    const bool kok = kc < p.K;
+    if (CONV) {
+      const int tap = kc / p.Ctot;
+      const int c = kc - tap * p.Ctot;
+      const int kh = tap / p.ks;
+      const int kw = tap - kh * p.ks;
+      const int Hv = p.up ? 2 * p.H : p.H, Wv = p.up ? 2 * p.W : p.W;
+      const bool second = c >= p.C1;
+      const AT* base = reinterpret_cast<const AT*>(second ? p.x2 : p.a);
+      const int Cs = second ? p.C2 : p.C1;
+      const int cs = second ? c - p.C1 : c;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int hv = xh[i] + kh, wv = xw[i] + kw;
+        const bool ok = kok && xok[i] && (unsigned)hv < (unsigned)Hv && (unsigned)wv < (unsigned)Wv;
+        if (ok) {
+          const int hs = p.up ? hv >> 1 : hv, ws = p.up ? wv >> 1 : wv;
+          xr[i].load(base + ((xrow_off[i] * p.H + hs) * p.W + ws) * Cs + cs);
+        } else {
+          xr[i].zero();
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (kok && xok[i]) {
+          xr[i].load(A + xrow_off[i] + kc);
+          if (NSPLIT == 2 && sizeof(AT) == 2) xr_lo[i] = *reinterpret_cast<const bf16x8*>(A_lo + xrow_off[i] + kc);
+        } else {
+          xr[i].zero();
+          if (NSPLIT == 2 && sizeof(AT) == 2) xr_lo[i] = zero8;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WNT; ++i) {
+      if (kok && wok[i]) {
+        wr[i] = *reinterpret_cast<const bf16x8*>(Wp + wrow_off[i] + kc);
+        if (NSPLIT == 2) wr_lo[i] = *reinterpret_cast<const bf16x8*>(Wlo + wrow_off[i] + kc);
+      } else {
+        wr[i] = zero8;
+        if (NSPLIT == 2) wr_lo[i] = zero8;
+      }
+    }
+  };
+
+  auto store_tile = [&](int stage) {
+    char* xs = smem + stage * STAGE_BYTES;
+    char* ws = xs + NSPLIT * XS_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = r0 + 32 * i;
+      const int off = lds_off(row, cc);
+      if constexpr (sizeof(AT) == 4) {
+        bf16x8 lo;
+        const crg_vec8<float>& xv = reinterpret_cast<const crg_vec8<float>&>(xr[i]);
+        bf16x8 hi = split_hi(xv, lo);
+        *reinterpret_cast<bf16x8*>(xs + off) = hi;
+        if (NSPLIT == 2) *reinterpret_cast<bf16x8*>(xs + XS_BYTES + off) = lo;
+      } else {
+        *reinterpret_cast<bf16x8*>(xs + off) = reinterpret_cast<const crg_vec8<bf16>&>(xr[i]).v;
+        if (NSPLIT == 2) *reinterpret_cast<bf16x8*>(xs + XS_BYTES + off) = xr_lo[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WNT; ++i) {
+      const int row = r0 + 32 * i;
+      const int off = lds_off(row, cc);
+      *reinterpret_cast<bf16x8*>(ws + off) = wr[i];
+      if (NSPLIT == 2) *reinterpret_cast<bf16x8*>(ws + WS_BYTES + off) = wr_lo[i];
+    }
+  };
+
+  f32x4 acc[WNT][4];
+#pragma unroll
+  for (int i = 0; i < WNT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int frow = lane & 15;
+  const int fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) load_tile(kt + 1);
+    const char* xs = smem + (kt & 1) * STAGE_BYTES;
+    const char* ws = xs + NSPLIT * XS_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 xf[4], xl[4], wf[WNT], wl[WNT];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int off = lds_off(wm * 64 + j * 16 + frow, ks * 4 + fq);
+        xf[j] = *reinterpret_cast<const bf16x8*>(xs + off);
+        if (NSPLIT == 2) xl[j] = *reinterpret_cast<const bf16x8*>(xs + XS_BYTES + off);
+      }
+#pragma unroll
+      for (int i = 0; i < WNT; ++i) {
+        const int off = lds_off(wn * (16 * WNT) + i * 16 + frow, ks * 4 + fq);
+        wf[i] = *reinterpret_cast<const bf16x8*>(ws + off);
+        if (NSPLIT == 2) wl[i] = *reinterpret_cast<const bf16x8*>(ws + WS_BYTES + off);
+      }
+#pragma unroll
+      for (int i = 0; i < WNT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (NSPLIT == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xl[j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (more) store_tile((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds rows n = ..+fq*4+{0..3}, column m = ..+frow of each 16x16 tile ----
+  YT* Y = reinterpret_cast<YT*>(p.y) + (long)bz * p.y_bs;
+  const YT* R = p.res ? reinterpret_cast<const YT*>(p.res) + (long)bz * p.r_bs : nullptr;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wm * 64 + j * 16 + frow;
+    if (m >= p.M) continue;
+    const float brow = (p.bias_mode == CRG_BIAS_ROW) ? p.bias[m] : 0.f;
+    const float* cv = p.cvec ? p.cvec + (long)(m / p.cvec_rows) * p.N : nullptr;
+    if (p.epi == CRG_EPI_GEGLU) {
+      // packed columns: [v 16 | g 16] groups; tiles (2u, 2u+1) of this wave are value / gate
+      if constexpr (WNT % 2 == 0) {
+#pragma unroll
+        for (int u = 0; u < WNT / 2; ++u) {
+          const int pn = n0 + wn * (16 * WNT) + u * 32 + fq * 4;  // packed column of the value tile
+          if (pn >= p.N) continue;
+          const int jn = (n0 + wn * (16 * WNT)) / 2 + u * 16 + fq * 4;  // output column
+          f32x4 v = acc[2 * u][j], g = acc[2 * u + 1][j];
+          if (p.bias_mode == CRG_BIAS_COL) {
+            v += *reinterpret_cast<const f32x4*>(p.bias + pn);
+            g += *reinterpret_cast<const f32x4*>(p.bias + pn + 16);
+          }
+          YT out[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) out[e] = (YT)(v[e] * crg_gelu_erf_f(g[e]));
+          YT* dst = Y + (long)m * p.ldy + jn;
+          if constexpr (sizeof(YT) == 2) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(out);
+          else *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<f32x4*>(out);
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int i = 0; i < WNT; ++i) {
+      const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      const bool full = (n + 4 <= p.N);
+      if (full) {
+        if (p.bias_mode == CRG_BIAS_COL) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        else if (p.bias_mode == CRG_BIAS_ROW) v += brow;
+        if (p.epi == CRG_EPI_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = crg_silu_f(v[e]);
+        }
+        if (cv) v += *reinterpret_cast<const f32x4*>(cv + n);
+        const long yo = (long)m * p.ldy + n;
+        if (R) {
+          const YT* rp = R + (long)m * p.ldr + n;
+          if (((p.ldr | n) & 3) == 0) {
+            if constexpr (sizeof(YT) == 2) {
+              bf16x4 r4 = *reinterpret_cast<const bf16x4*>(rp);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+            } else {
+              v += *reinterpret_cast<const f32x4*>(rp);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rp[e];
+          }
+        }
+        if (((p.ldy | n) & 3) == 0) {
+          if constexpr (sizeof(YT) == 2) {
+            bf16x4 o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o4[e] = (bf16)v[e];
+            *reinterpret_cast<bf16x4*>(Y + yo) = o4;
+          } else {
+            *reinterpret_cast<f32x4*>(Y + yo) = v;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Y[yo + e] = (YT)v[e];
+        }
+      } else {
+        for (int e = 0; e < 4 && n + e < p.N; ++e) {
+          float s = v[e];
+          if (p.bias_mode == CRG_BIAS_COL) s += p.bias[n + e];
+          else if (p.bias_mode == CRG_BIAS_ROW) s += brow;
+          if (p.epi == CRG_EPI_SILU) s = crg_silu_f(s);
+          if (cv) s += cv[n + e];
+          if (R) s += (float)R[(long)m * p.ldr + n + e];
+          Y[(long)m * p.ldy + n + e] = (YT)s;
+        }
+      }
+    }
+  }
+}
+
+template <int WNT, int NSPLIT, typename AT, typename YT, bool CONV>
+int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch) {
+  constexpr int BN = 32 * WNT;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  const size_t lds = 2 * NSPLIT * (BM + BN) * 128;
+  auto kern = gemm_kernel<WNT, NSPLIT, AT, YT, CONV>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", lds, hipGetErrorString(e));
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_n * p.tiles_m, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  CRG_CHECK_LAUNCH(ctx, "gemm");
+  return 0;
+}
+
+template <int NSPLIT, typename AT, typename YT, bool CONV>
+int launch_wnt(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch) {
+  // 160-wide tiles when they divide N (all UNet widths are multiples of 320), else 128-wide.
+  const bool geglu = p.epi == CRG_EPI_GEGLU;
+  if (!geglu && p.N % 160 == 0) return launch<5, NSPLIT, AT, YT, CONV>(ctx, st, p, batch);
+  return launch<4, NSPLIT, AT, YT, CONV>(ctx, st, p, batch);
+}
+
+template <bool CONV>
+int dispatch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, int a_dtype, int y_dtype, int prec) {
+  if (prec == CRG_PREC_BF16) {
+    if (a_dtype == CRG_BF16 && y_dtype == CRG_BF16) return launch_wnt<1, bf16, bf16, CONV>(ctx, st, p, batch);
+    if (a_dtype == CRG_BF16 && y_dtype == CRG_F32) return launch_wnt<1, bf16, float, CONV>(ctx, st, p, batch);
+    if (a_dtype == CRG_F32 && y_dtype == CRG_BF16) return launch_wnt<1, float, bf16, CONV>(ctx, st, p, batch);
+    if (a_dtype == CRG_F32 && y_dtype == CRG_F32) return launch_wnt<1, float, float, CONV>(ctx, st, p, batch);
+  } else if (prec == CRG_PREC_BF16X3) {
+    if (a_dtype == CRG_F32 && y_dtype == CRG_F32) return launch_wnt<2, float, float, CONV>(ctx, st, p, batch);
+    if (!CONV && a_dtype == CRG_BF16 && y_dtype == CRG_F32 && p.a_is_weight)
+      return launch_wnt<2, bf16, float, false>(ctx, st, p, batch);
+  }
+  return crg_fail(ctx, -22, "gemm/conv: unsupported dtype/precision combination a=%d y=%d prec=%d", a_dtype, y_dtype, prec);
+}
+
+}  // namespace
+
+extern "C" int crg_gemm(crg_ctx* ctx, void* stream, const crg_gemm_args* a) {
+  if (!ctx || !a) return -22;
+  CRG_REQUIRE(ctx, a->M > 0 && a->N > 0 && a->K > 0 && a->batch > 0, "gemm: empty problem M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
+  CRG_REQUIRE(ctx, a->K % 8 == 0, "gemm: K=%d must be a multiple of 8", a->K);
+  const int ae = (a->a_dtype == CRG_F32) ? 4 : 8;  // elements per 16 B
+  CRG_REQUIRE(ctx, a->lda % ae == 0 && a->ldw % 8 == 0, "gemm: lda=%ld / ldw=%ld must keep rows 16-byte aligned", (long)a->lda, (long)a->ldw);
+  CRG_REQUIRE(ctx, ((uintptr_t)a->a & 15) == 0 && ((uintptr_t)a->w & 15) == 0, "gemm: operand pointers must be 16-byte aligned");
+  CRG_REQUIRE(ctx, a->prec == CRG_PREC_BF16 || a->w_lo, "gemm: BF16X3 needs the lo weight plane");
+  if (a->epilogue == CRG_EPI_GEGLU) {
+    CRG_REQUIRE(ctx, a->N % 32 == 0, "gemm: GEGLU needs packed N %% 32 == 0 (got %d)", a->N);
+    CRG_REQUIRE(ctx, !a->residual, "gemm: GEGLU epilogue takes no residual");
+  }
+  if (a->bias && a->bias_mode == CRG_BIAS_COL)
+    CRG_REQUIRE(ctx, ((uintptr_t)a->bias & 15) == 0 && a->N % 4 == 0, "gemm: column bias needs 16-byte alignment and N %% 4 == 0");
+  GemmP p{};
+  p.a = a->a; p.a_lo = a->a_lo; p.lda = a->lda; p.a_bs = a->a_bstride;
+  p.w = (const bf16*)a->w; p.w_lo = (const bf16*)a->w_lo; p.ldw = a->ldw; p.w_bs = a->w_bstride;
+  p.bias = a->bias; p.bias_mode = a->bias ? a->bias_mode : CRG_BIAS_NONE;
+  p.res = a->residual; p.ldr = a->ldr; p.r_bs = a->r_bstride;
+  p.y = a->y; p.ldy = a->ldy; p.y_bs = a->y_bstride;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.epi = a->epilogue;
+  p.cvec = nullptr; p.cvec_rows = 1; p.a_is_weight = a->a_is_weight;
+  const double flops = 2.0 * a->M * (double)a->N * a->K * a->batch;
+  const double bytes = ((double)a->M * a->K * crg_dtype_size(a->a_dtype) + (double)a->N * a->K * 2 +
+                        (double)a->M * a->N * crg_dtype_size(a->y_dtype) * (a->residual ? 2 : 1)) * a->batch;
+  crg_prof_scope ps(ctx, (hipStream_t)stream, CRG_K_GEMM, flops, bytes);
+  return dispatch<false>(ctx, (hipStream_t)stream, p, a->batch, a->a_dtype, a->y_dtype, a->prec);
+}
+
+extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
+  if (!ctx || !a) return -22;
+  const int Ctot = a->C1 + a->C2;
+  CRG_REQUIRE(ctx, a->N > 0 && a->H > 0 && a->W > 0 && a->Cout > 0 && Ctot > 0, "conv2d: empty problem");
+  CRG_REQUIRE(ctx, a->ksize == 3 || a->ksize == 1, "conv2d: ksize %d unsupported", a->ksize);
+  CRG_REQUIRE(ctx, a->C1 % 8 == 0 && a->C2 % 8 == 0, "conv2d: channel counts must be multiples of 8 (C1=%d C2=%d); use crg_conv3x3_small", a->C1, a->C2);
+  CRG_REQUIRE(ctx, (a->C2 == 0) == (a->x2 == nullptr), "conv2d: x2/C2 mismatch");
+  CRG_REQUIRE(ctx, a->prec == CRG_PREC_BF16 || a->w_lo, "conv2d: BF16X3 needs the lo weight plane");
+  CRG_REQUIRE(ctx, a->Cout % 4 == 0, "conv2d: Cout=%d must be a multiple of 4; use crg_conv3x3_small", a->Cout);
+  CRG_REQUIRE(ctx, ((uintptr_t)a->x & 15) == 0 && ((uintptr_t)a->w & 15) == 0 && ((uintptr_t)a->bias & 15) == 0 && ((uintptr_t)a->cvec & 15) == 0,
+              "conv2d: pointers must be 16-byte aligned");
+  const int Hv = a->upsample2x ? 2 * a->H : a->H, Wv = a->upsample2x ? 2 * a->W : a->W;
+  CRG_REQUIRE(ctx, a->Ho > 0 && a->Wo > 0 && (a->Ho - 1) * a->stride - a->pad_t < Hv && (a->Wo - 1) * a->stride - a->pad_l < Wv,
+              "conv2d: output %dx%d inconsistent with input %dx%d stride %d", a->Ho, a->Wo, Hv, Wv, a->stride);
+  GemmP p{};
+  p.a = a->x; p.x2 = a->x2; p.C1 = a->C1; p.C2 = a->C2; p.Ctot = Ctot;
+  p.w = (const bf16*)a->w; p.w_lo = (const bf16*)a->w_lo; p.ldw = (long)a->ksize * a->ksize * Ctot; p.w_bs = 0;
+  p.bias = a->bias; p.bias_mode = a->bias ? CRG_BIAS_COL : CRG_BIAS_NONE;
+  p.res = a->residual; p.ldr = a->Cout; p.r_bs = 0;
+  p.y = a->y; p.ldy = a->Cout; p.y_bs = 0;
+  p.M = a->N * a->Ho * a->Wo; p.N = a->Cout; p.K = a->ksize * a->ksize * Ctot; p.epi = CRG_EPI_NONE;
+  p.cvec = a->cvec; p.cvec_rows = a->Ho * a->Wo;
+  p.H = a->H; p.W = a->W; p.Ho = a->Ho; p.Wo = a->Wo; p.ks = a->ksize; p.stride = a->stride;
+  p.pad_t = a->pad_t; p.pad_l = a->pad_l; p.up = a->upsample2x;
+  const double flops = 2.0 * p.M * (double)p.N * p.K;
+  const double bytes = (double)a->N * a->H * a->W * Ctot * crg_dtype_size(a->x_dtype) + (double)p.N * p.K * 2 +
+                       (double)p.M * p.N * crg_dtype_size(a->y_dtype) * (a->residual ? 2 : 1);
+  crg_prof_scope ps(ctx, (hipStream_t)stream, CRG_K_CONV, flops, bytes);
+  return dispatch<true>(ctx, (hipStream_t)stream, p, 1, a->x_dtype, a->y_dtype, a->prec);
+}

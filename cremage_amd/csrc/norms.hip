@@ -1,0 +1,292 @@
+// HBM-bound normalisation kernels: GroupNorm(+SiLU) over channels-last images, LayerNorm over token
+// rows, row softmax.  All loads/stores are 16 bytes per lane (8 bf16 / 2x4 f32), rows are walked
+// with consecutive lanes on consecutive channels (fully coalesced NHWC rows).
+#include "crg_common.h"
+
+namespace {
+
+constexpr int GN_MAX_GROUPS = 32;
+
+// ---- GroupNorm pass 1: partial (sum, sumsq) of (x - K_g) per (sample, chunk, group) --------------
+// K_g = first element of group g in the sample's first pixel: the classic shifted-data form, so the
+// fp32 accumulation error scales with the spread around K_g and not with |mean|^2 / var.
+// grid (chunks, N); thread = (row lane, 8-channel column).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, int C, int HW,
+                                                       int groups, int rows_per_chunk, float* __restrict__ part,
+                                                       float* __restrict__ kbuf) {
+  __shared__ float s1[GN_MAX_GROUPS], s2[GN_MAX_GROUPS], shiftv[GN_MAX_GROUPS];
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int tpr = C >> 3;                 // threads per row
+  const int rpi = 256 / tpr;              // rows per iteration
+  const int t = threadIdx.x;
+  const int col = t % tpr, rl = t / tpr;
+  const int gs = C / groups;
+  const int C2 = C - C1;
+  if (t < groups) {
+    s1[t] = 0.f;
+    s2[t] = 0.f;
+    const int c = t * gs;
+    shiftv[t] = (c < C1) ? (float)x[(long)n * HW * C1 + c] : (float)x2[(long)n * HW * C2 + (c - C1)];
+    if (chunk == 0) kbuf[n * groups + t] = shiftv[t];  // the apply pass must not re-read x (y may alias x)
+  }
+  __syncthreads();
+  const int c0 = col * 8;
+  float a1[8], a2[8], sh[8];
+  int gid[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    a1[e] = a2[e] = 0.f;
+    gid[e] = (c0 + e) / gs;
+    sh[e] = shiftv[gid[e] < groups ? gid[e] : 0];
+  }
+  if (rl < rpi) {
+    const bool second = c0 >= C1;
+    const T* base = second ? x2 + (long)n * HW * C2 + (c0 - C1) : x + (long)n * HW * C1 + c0;
+    const int Cs = second ? C2 : C1;
+    const int r_begin = chunk * rows_per_chunk;
+    const int r_end = min(HW, r_begin + rows_per_chunk);
+    for (int r = r_begin + rl; r < r_end; r += rpi) {
+      crg_vec8<T> v;
+      v.load(base + (long)r * Cs);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v.get(e) - sh[e];
+        a1[e] += d;
+        a2[e] += d * d;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      atomicAdd(&s1[gid[e]], a1[e]);
+      atomicAdd(&s2[gid[e]], a2[e]);
+    }
+  }
+  __syncthreads();
+  if (t < groups) {
+    float* o = part + (((long)n * gridDim.x + chunk) * groups + t) * 2;
+    o[0] = s1[t];
+    o[1] = s2[t];
+  }
+}
+
+// ---- GroupNorm pass 2: finalise statistics (fp64 combine) and apply affine (+SiLU) ---------------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, int C, int HW,
+                                                       int groups, int rows_per_block, int n_chunks,
+                                                       const float* __restrict__ part, const float* __restrict__ kbuf,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, int silu, T* __restrict__ y) {
+  __shared__ float meanv[GN_MAX_GROUPS], rstdv[GN_MAX_GROUPS];
+  const int n = blockIdx.y;
+  const int t = threadIdx.x;
+  const int gs = C / groups;
+  const int C2 = C - C1;
+  if (t < groups) {
+    const double K = (double)kbuf[n * groups + t];
+    double a = 0.0, b = 0.0;
+    for (int ch = 0; ch < n_chunks; ++ch) {
+      const float* pp = part + (((long)n * n_chunks + ch) * groups + t) * 2;
+      a += (double)pp[0];
+      b += (double)pp[1];
+    }
+    const double cnt = (double)HW * gs;
+    const double md = a / cnt;
+    double var = b / cnt - md * md;
+    if (var < 0.0) var = 0.0;
+    meanv[t] = (float)(K + md);
+    rstdv[t] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int tpr = C >> 3;
+  const int rpi = 256 / tpr;
+  const int col = t % tpr, rl = t / tpr;
+  if (rl >= rpi) return;
+  const int c0 = col * 8;
+  float sc[8], sf[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int g = (c0 + e) / gs;
+    const float ga = gamma[c0 + e], be = beta[c0 + e];
+    sc[e] = rstdv[g] * ga;
+    sf[e] = be - meanv[g] * rstdv[g] * ga;
+  }
+  const bool second = c0 >= C1;
+  const T* base = second ? x2 + (long)n * HW * C2 + (c0 - C1) : x + (long)n * HW * C1 + c0;
+  const int Cs = second ? C2 : C1;
+  T* yb = y + (long)n * HW * C + c0;
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(HW, r_begin + rows_per_block);
+  for (int r = r_begin + rl; r < r_end; r += rpi) {
+    crg_vec8<T> v, o;
+    v.load(base + (long)r * Cs);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = v.get(e) * sc[e] + sf[e];
+      if (silu) f = crg_silu_f(f);
+      o.set(e, f);
+    }
+    o.store(yb + (long)r * C);
+  }
+}
+
+// ---- LayerNorm: one wave per row, row kept in registers (dim <= 64 lanes * 8 * LN_MAXC) ----------
+constexpr int LN_MAXC = 4;  // dim <= 2048
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ y, long rows, int dim,
+                                                        float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = dim >> 3;
+  const T* xr = x + row * dim;
+  crg_vec8<T> v[LN_MAXC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      v[i].load(xr + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i].get(e);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)dim;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[i].get(e) - mean;
+        q += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q / (float)dim + eps);
+  T* yr = y + row * dim;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      crg_vec8<T> o;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + ch * 8), b1 = *reinterpret_cast<const f32x4*>(beta + ch * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float ga = e < 4 ? g0[e] : g1[e - 4], be = e < 4 ? b0[e] : b1[e - 4];
+        o.set(e, (v[i].get(e) - mean) * rstd * ga + be);
+      }
+      o.store(yr + ch * 8);
+    }
+  }
+}
+
+// ---- row softmax: one block per row, y = softmax(x * scale) -----------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int cols, long ld, float scale) {
+  __shared__ float red[8];
+  const long row = blockIdx.x;
+  const T* xr = x + row * ld;
+  T* yr = y + row * ld;
+  const int t = threadIdx.x;
+  float mx = -INFINITY;
+  for (int c = t; c < cols; c += 256) mx = fmaxf(mx, (float)xr[c] * scale);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((t & 63) == 0) red[t >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = t; c < cols; c += 256) s += __expf((float)xr[c] * scale - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((t & 63) == 0) red[4 + (t >> 6)] = s;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int c = t; c < cols; c += 256) yr[c] = (T)(__expf((float)xr[c] * scale - mx) * inv);
+}
+
+}  // namespace
+
+extern "C" int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* gamma,
+                             const float* beta, void* y, int N, int HW, int C, int groups, float eps, int fuse_silu,
+                             int dtype) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, N > 0 && HW > 0 && C > 0, "groupnorm: empty input");
+  CRG_REQUIRE(ctx, groups > 0 && groups <= GN_MAX_GROUPS && C % groups == 0, "groupnorm: groups=%d C=%d unsupported", groups, C);
+  CRG_REQUIRE(ctx, C % 8 == 0 && C <= 2048 * 8 && (C >> 3) <= 256, "groupnorm: C=%d must be a multiple of 8 and <= 2048", C);
+  if (!x2) C1 = C;
+  CRG_REQUIRE(ctx, C1 > 0 && C1 <= C && C1 % 8 == 0 && (C - C1) % 8 == 0, "groupnorm: concat split C1=%d of C=%d unsupported", C1, C);
+  CRG_REQUIRE(ctx, dtype == CRG_BF16 || dtype == CRG_F32, "groupnorm: dtype %d unsupported", dtype);
+  // rows per block: aim for >= ~1024 blocks over the chip, at least 8 rows each
+  int chunks = (HW + 63) / 64;
+  while ((long)chunks * N < 1024 && chunks < HW / 8) chunks *= 2;
+  if (chunks > HW) chunks = HW;
+  if (chunks < 1) chunks = 1;
+  const int rpc = (HW + chunks - 1) / chunks;
+  chunks = (HW + rpc - 1) / rpc;
+  float* part = (float*)crg_scratch(ctx, ((size_t)N * chunks * groups * 2 + (size_t)N * groups) * sizeof(float));
+  if (!part) return crg_fail(ctx, -12, "groupnorm: out of scratch");
+  float* kbuf = part + (size_t)N * chunks * groups * 2;
+  hipStream_t st = (hipStream_t)stream;
+  const double elems = (double)N * HW * C;
+  const size_t es = crg_dtype_size(dtype);
+  crg_prof_scope ps(ctx, st, CRG_K_GROUPNORM, 8.0 * elems, elems * es * 3);
+  dim3 grid(chunks, N);
+  if (dtype == CRG_BF16) {
+    hipLaunchKernelGGL(gn_stats_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (const bf16*)x2, C1, C, HW, groups, rpc, part, kbuf);
+    hipLaunchKernelGGL(gn_apply_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (const bf16*)x2, C1, C, HW, groups, rpc, chunks,
+                       part, kbuf, gamma, beta, eps, fuse_silu, (bf16*)y);
+  } else {
+    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)x2, C1, C, HW, groups, rpc, part, kbuf);
+    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)x2, C1, C, HW, groups, rpc, chunks,
+                       part, kbuf, gamma, beta, eps, fuse_silu, (float*)y);
+  }
+  CRG_CHECK_LAUNCH(ctx, "groupnorm");
+  return 0;
+}
+
+extern "C" int crg_layernorm(crg_ctx* ctx, void* stream, const void* x, const float* gamma, const float* beta, void* y,
+                             int64_t rows, int dim, float eps, int dtype) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, rows > 0 && dim > 0, "layernorm: empty input");
+  CRG_REQUIRE(ctx, dim % 8 == 0 && dim <= 64 * 8 * LN_MAXC, "layernorm: dim=%d must be a multiple of 8 and <= %d", dim, 64 * 8 * LN_MAXC);
+  CRG_REQUIRE(ctx, ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0, "layernorm: gamma/beta must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const double elems = (double)rows * dim;
+  crg_prof_scope ps(ctx, st, CRG_K_LAYERNORM, 8.0 * elems, elems * crg_dtype_size(dtype) * 2);
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (dtype == CRG_BF16)
+    hipLaunchKernelGGL(layernorm_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, gamma, beta, (bf16*)y, (long)rows, dim, eps);
+  else if (dtype == CRG_F32)
+    hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y, (long)rows, dim, eps);
+  else
+    return crg_fail(ctx, -22, "layernorm: dtype %d unsupported", dtype);
+  CRG_CHECK_LAUNCH(ctx, "layernorm");
+  return 0;
+}
+
+extern "C" int crg_softmax_rows(crg_ctx* ctx, void* stream, const void* x, void* y, int64_t rows, int cols, int64_t ld,
+                                float scale, int dtype) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, rows > 0 && cols > 0 && ld >= cols, "softmax_rows: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const double elems = (double)rows * cols;
+  crg_prof_scope ps(ctx, st, CRG_K_SOFTMAX, 5.0 * elems, elems * crg_dtype_size(dtype) * 2);
+  if (dtype == CRG_BF16)
+    hipLaunchKernelGGL(softmax_rows_kernel<bf16>, dim3((unsigned)rows), dim3(256), 0, st, (const bf16*)x, (bf16*)y, cols, (long)ld, scale);
+  else if (dtype == CRG_F32)
+    hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)x, (float*)y, cols, (long)ld, scale);
+  else
+    return crg_fail(ctx, -22, "softmax_rows: dtype %d unsupported", dtype);
+  CRG_CHECK_LAUNCH(ctx, "softmax_rows");
+  return 0;
+}

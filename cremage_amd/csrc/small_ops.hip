@@ -1,0 +1,312 @@
+// Small / HBM-bound helpers: thin-channel 3x3 conv (conv_in / conv_out), timestep embedding, SiLU,
+// NCHW<->NHWC boundary transposes with dtype conversion, affine+clamp cast.
+#include "crg_common.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ float ldf(const T* p) { return (float)*p; }
+
+// ---- conv3x3, Cin <= 8 (conv_in): thread = (pixel, 8 output channels); weights in LDS as [tap*Cin][Cout]
+template <typename XT, typename YT>
+__global__ __launch_bounds__(256) void conv_small_cin_kernel(const XT* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, YT* __restrict__ y, int N, int H, int W,
+                                                             int Cin, int Cout, int ks) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [ks*ks*Cin][Cout]
+  const int taps = ks * ks, pad = ks / 2;
+  for (int i = threadIdx.x; i < taps * Cin * Cout; i += 256) {
+    // i -> (k = tap*Cin+ci, co); source [co][ci][tap]
+    const int co = i % Cout, k = i / Cout;
+    const int tap = k / Cin, ci = k - tap * Cin;
+    wl[i] = w[((long)co * Cin + ci) * taps + tap];
+  }
+  __syncthreads();
+  const int cg = Cout >> 3;  // 8-channel groups
+  const long total = (long)N * H * W * cg;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int g = (int)(idx % cg);
+    const long pix = idx / cg;
+    const int wo = (int)(pix % W);
+    const int ho = (int)((pix / W) % H);
+    const int n = (int)(pix / ((long)W * H));
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[g * 8 + e] : 0.f;
+    for (int tap = 0; tap < taps; ++tap) {
+      const int hi = ho + tap / ks - pad, wi = wo + tap % ks - pad;
+      if ((unsigned)hi >= (unsigned)H || (unsigned)wi >= (unsigned)W) continue;
+      const XT* xp = x + (((long)n * H + hi) * W + wi) * Cin;
+      for (int ci = 0; ci < Cin; ++ci) {
+        const float xv = ldf(xp + ci);
+        const float* wp = wl + (tap * Cin + ci) * Cout + g * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += xv * wp[e];
+      }
+    }
+    YT* yp = y + pix * Cout + g * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) yp[e] = (YT)acc[e];
+  }
+}
+
+// ---- conv3x3, Cout <= 8 (conv_out): thread = pixel, all output channels; weights in LDS [tap][Cin][Cout]
+template <typename XT, typename YT, int CO>
+__global__ __launch_bounds__(256) void conv_small_cout_kernel(const XT* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, YT* __restrict__ y, int N, int H, int W,
+                                                              int Cin, int Cout, int ks) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [ks*ks][Cin][CO]
+  const int taps = ks * ks, pad = ks / 2;
+  for (int i = threadIdx.x; i < taps * Cin * CO; i += 256) {
+    const int co = i % CO, k = i / CO;
+    const int tap = k / Cin, ci = k - tap * Cin;
+    wl[i] = co < Cout ? w[((long)co * Cin + ci) * taps + tap] : 0.f;
+  }
+  __syncthreads();
+  const long total = (long)N * H * W;
+  for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (long)gridDim.x * 256) {
+    const int wo = (int)(pix % W);
+    const int ho = (int)((pix / W) % H);
+    const int n = (int)(pix / ((long)W * H));
+    float acc[CO];
+#pragma unroll
+    for (int e = 0; e < CO; ++e) acc[e] = (bias && e < Cout) ? bias[e] : 0.f;
+    for (int tap = 0; tap < taps; ++tap) {
+      const int hi = ho + tap / ks - pad, wi = wo + tap % ks - pad;
+      if ((unsigned)hi >= (unsigned)H || (unsigned)wi >= (unsigned)W) continue;
+      const XT* xp = x + (((long)n * H + hi) * W + wi) * Cin;
+      const float* wt = wl + tap * Cin * CO;
+      if ((Cin & 7) == 0) {
+        for (int c0 = 0; c0 < Cin; c0 += 8) {
+          crg_vec8<XT> v;
+          v.load(xp + c0);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xv = v.get(j);
+#pragma unroll
+            for (int e = 0; e < CO; ++e) acc[e] += xv * wt[(c0 + j) * CO + e];
+          }
+        }
+      } else {
+        for (int ci = 0; ci < Cin; ++ci) {
+          const float xv = ldf(xp + ci);
+#pragma unroll
+          for (int e = 0; e < CO; ++e) acc[e] += xv * wt[ci * CO + e];
+        }
+      }
+    }
+    YT* yp = y + pix * Cout;
+#pragma unroll
+    for (int e = 0; e < CO; ++e)
+      if (e < Cout) yp[e] = (YT)acc[e];
+  }
+}
+
+template <typename YT>
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, YT* __restrict__ out, int B, int dim) {
+  const int half = dim / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * dim) return;
+  const int b = idx / dim, j = idx - b * dim;
+  float v = 0.f;
+  if (j < 2 * half) {
+    const int i = j < half ? j : j - half;
+    // freqs = exp(-ln(10000) * i / half) in fp32, as util.py:162-164 builds them
+    const float f = expf(-9.210340371976184f * (float)i / (float)half);
+    const float a = t[b] * f;
+    v = j < half ? cosf(a) : sinf(a);
+  }
+  out[idx] = (YT)v;
+}
+
+template <typename T>
+__global__ void silu_kernel(const T* __restrict__ x, T* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = (T)crg_silu_f((float)x[i]);
+}
+
+// NCHW -> NHWC via a 32x32 LDS tile transpose: src [N][C][HW], dst [N][HW][C]
+template <typename ST, typename DT>
+__global__ __launch_bounds__(256) void transpose_kernel(const ST* __restrict__ src, DT* __restrict__ dst, int R, int Cc) {
+  // src viewed as [N][R][Cc], dst as [N][Cc][R]
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const ST* s = src + (long)n * R * Cc;
+  DT* d = dst + (long)n * R * Cc;
+  for (int i = ty; i < 32; i += 8) {
+    const int rr = r0 + i, cc = c0 + tx;
+    tile[i][tx] = (rr < R && cc < Cc) ? (float)s[(long)rr * Cc + cc] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int cc = c0 + i, rr = r0 + tx;
+    if (rr < R && cc < Cc) d[(long)cc * R + rr] = (DT)tile[tx][i];
+  }
+}
+
+template <typename ST, typename DT>
+__global__ void affine_cast_kernel(const ST* __restrict__ x, DT* __restrict__ y, long n, float a, float b, float lo, float hi) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = (float)x[i] * a + b;
+    v = fminf(fmaxf(v, lo), hi);
+    y[i] = (DT)v;
+  }
+}
+
+template <typename T>
+__global__ void axpby_kernel(const T* __restrict__ x, T* __restrict__ y, long n, float a, float b) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = (T)(a * (float)x[i] + b * (float)y[i]);
+}
+
+template <typename F>
+int by_dtype2(crg_ctx* ctx, int sdt, int ddt, const char* what, F&& f) {
+  if (sdt == CRG_BF16 && ddt == CRG_BF16) return f((const bf16*)nullptr, (bf16*)nullptr);
+  if (sdt == CRG_BF16 && ddt == CRG_F32) return f((const bf16*)nullptr, (float*)nullptr);
+  if (sdt == CRG_F32 && ddt == CRG_BF16) return f((const float*)nullptr, (bf16*)nullptr);
+  if (sdt == CRG_F32 && ddt == CRG_F32) return f((const float*)nullptr, (float*)nullptr);
+  return crg_fail(ctx, -22, "%s: unsupported dtype pair %d -> %d", what, sdt, ddt);
+}
+
+inline int grid_for(long n) {
+  long g = (n + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" int crg_conv_small(crg_ctx* ctx, void* stream, const void* x, const float* w, const float* bias, void* y,
+                              int N, int H, int W, int Cin, int Cout, int ksize, int x_dtype, int y_dtype) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv_small: empty problem");
+  CRG_REQUIRE(ctx, Cin <= 8 || Cout <= 8, "conv_small: needs Cin <= 8 or Cout <= 8 (Cin=%d Cout=%d)", Cin, Cout);
+  hipStream_t st = (hipStream_t)stream;
+  const int ks = ksize;
+  CRG_REQUIRE(ctx, ks == 1 || ks == 3, "conv_small: ksize %d unsupported", ks);
+  const double flops = 2.0 * N * H * W * (double)Cin * Cout * ks * ks;
+  const double bytes = (double)N * H * W * (Cin * crg_dtype_size(x_dtype) + Cout * crg_dtype_size(y_dtype));
+  crg_prof_scope ps(ctx, st, CRG_K_CONV_SMALL, flops, bytes);
+  int rc;
+  if (Cout <= 8) {
+    const size_t lds = (size_t)ks * ks * Cin * 8 * sizeof(float);
+    CRG_REQUIRE(ctx, lds <= 160 * 1024, "conv_small: Cin=%d too large for the LDS weight image", Cin);
+    if ((Cin & 7) == 0) CRG_REQUIRE(ctx, ((uintptr_t)x & 15) == 0, "conv_small: x must be 16-byte aligned");
+    rc = by_dtype2(ctx, x_dtype, y_dtype, "conv_small", [&](auto* xs, auto* ys) {
+      using XT = std::remove_const_t<std::remove_pointer_t<decltype(xs)>>;
+      using YT = std::remove_pointer_t<decltype(ys)>;
+      auto kern = conv_small_cout_kernel<XT, YT, 8>;
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, dim3(grid_for((long)N * H * W)), dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cin, Cout, ks);
+      return 0;
+    });
+  } else {
+    CRG_REQUIRE(ctx, Cout % 8 == 0, "conv_small: Cout=%d must be a multiple of 8 when Cin <= 8", Cout);
+    const size_t lds = (size_t)ks * ks * Cin * Cout * sizeof(float);
+    CRG_REQUIRE(ctx, lds <= 160 * 1024, "conv_small: Cout=%d too large for the LDS weight image", Cout);
+    rc = by_dtype2(ctx, x_dtype, y_dtype, "conv_small", [&](auto* xs, auto* ys) {
+      using XT = std::remove_const_t<std::remove_pointer_t<decltype(xs)>>;
+      using YT = std::remove_pointer_t<decltype(ys)>;
+      auto kern = conv_small_cin_kernel<XT, YT>;
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, dim3(grid_for((long)N * H * W * (Cout / 8))), dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cin, Cout, ks);
+      return 0;
+    });
+  }
+  if (rc) return rc;
+  CRG_CHECK_LAUNCH(ctx, "conv_small");
+  return 0;
+}
+
+extern "C" int crg_timestep_embedding(crg_ctx* ctx, void* stream, const float* t, void* out, int B, int dim, int dtype) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, B > 0 && dim > 0, "timestep_embedding: empty");
+  hipStream_t st = (hipStream_t)stream;
+  crg_prof_scope ps(ctx, st, CRG_K_ELEMENTWISE, 4.0 * B * dim, (double)B * dim * crg_dtype_size(dtype));
+  const int n = B * dim;
+  if (dtype == CRG_F32)
+    hipLaunchKernelGGL(timestep_embedding_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, st, t, (float*)out, B, dim);
+  else if (dtype == CRG_BF16)
+    hipLaunchKernelGGL(timestep_embedding_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, st, t, (bf16*)out, B, dim);
+  else
+    return crg_fail(ctx, -22, "timestep_embedding: dtype %d unsupported", dtype);
+  CRG_CHECK_LAUNCH(ctx, "timestep_embedding");
+  return 0;
+}
+
+extern "C" int crg_silu(crg_ctx* ctx, void* stream, const void* x, void* y, int64_t n, int dtype) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, n > 0, "silu: empty");
+  hipStream_t st = (hipStream_t)stream;
+  crg_prof_scope ps(ctx, st, CRG_K_ELEMENTWISE, 4.0 * n, 2.0 * n * crg_dtype_size(dtype));
+  if (dtype == CRG_F32)
+    hipLaunchKernelGGL(silu_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)x, (float*)y, (long)n);
+  else if (dtype == CRG_BF16)
+    hipLaunchKernelGGL(silu_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16*)x, (bf16*)y, (long)n);
+  else
+    return crg_fail(ctx, -22, "silu: dtype %d unsupported", dtype);
+  CRG_CHECK_LAUNCH(ctx, "silu");
+  return 0;
+}
+
+static int transpose_impl(crg_ctx* ctx, void* stream, const void* src, void* dst, int N, int R, int Cc, int sdt, int ddt,
+                          const char* what) {
+  CRG_REQUIRE(ctx, N > 0 && R > 0 && Cc > 0, "%s: empty", what);
+  hipStream_t st = (hipStream_t)stream;
+  const double elems = (double)N * R * Cc;
+  crg_prof_scope ps(ctx, st, CRG_K_ELEMENTWISE, 0.0, elems * (crg_dtype_size(sdt) + crg_dtype_size(ddt)));
+  dim3 grid((Cc + 31) / 32, (R + 31) / 32, N);
+  int rc = by_dtype2(ctx, sdt, ddt, what, [&](auto* xs, auto* ys) {
+    using ST = std::remove_const_t<std::remove_pointer_t<decltype(xs)>>;
+    using DT = std::remove_pointer_t<decltype(ys)>;
+    hipLaunchKernelGGL((transpose_kernel<ST, DT>), grid, dim3(256), 0, st, (const ST*)src, (DT*)dst, R, Cc);
+    return 0;
+  });
+  if (rc) return rc;
+  CRG_CHECK_LAUNCH(ctx, what);
+  return 0;
+}
+
+extern "C" int crg_nchw_to_nhwc(crg_ctx* ctx, void* stream, const void* src, void* dst, int N, int C, int HW, int src_dtype,
+                                int dst_dtype) {
+  if (!ctx) return -22;
+  return transpose_impl(ctx, stream, src, dst, N, C, HW, src_dtype, dst_dtype, "nchw_to_nhwc");
+}
+
+extern "C" int crg_nhwc_to_nchw(crg_ctx* ctx, void* stream, const void* src, void* dst, int N, int C, int HW, int src_dtype,
+                                int dst_dtype) {
+  if (!ctx) return -22;
+  return transpose_impl(ctx, stream, src, dst, N, HW, C, src_dtype, dst_dtype, "nhwc_to_nchw");
+}
+
+extern "C" int crg_affine_cast(crg_ctx* ctx, void* stream, const void* x, void* y, int64_t n, float a, float b, float lo,
+                               float hi, int src_dtype, int dst_dtype) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, n > 0, "affine_cast: empty");
+  hipStream_t st = (hipStream_t)stream;
+  crg_prof_scope ps(ctx, st, CRG_K_ELEMENTWISE, 2.0 * n, (double)n * (crg_dtype_size(src_dtype) + crg_dtype_size(dst_dtype)));
+  int rc = by_dtype2(ctx, src_dtype, dst_dtype, "affine_cast", [&](auto* xs, auto* ys) {
+    using ST = std::remove_const_t<std::remove_pointer_t<decltype(xs)>>;
+    using DT = std::remove_pointer_t<decltype(ys)>;
+    hipLaunchKernelGGL((affine_cast_kernel<ST, DT>), dim3(grid_for(n)), dim3(256), 0, st, (const ST*)x, (DT*)y, (long)n, a, b, lo, hi);
+    return 0;
+  });
+  if (rc) return rc;
+  CRG_CHECK_LAUNCH(ctx, "affine_cast");
+  return 0;
+}
+
+extern "C" int crg_axpby(crg_ctx* ctx, void* stream, const void* x, void* y, int64_t n, float a, float b, int dtype) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, n > 0, "axpby: empty");
+  hipStream_t st = (hipStream_t)stream;
+  crg_prof_scope ps(ctx, st, CRG_K_ELEMENTWISE, 3.0 * n, 3.0 * n * crg_dtype_size(dtype));
+  if (dtype == CRG_F32)
+    hipLaunchKernelGGL(axpby_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)x, (float*)y, (long)n, a, b);
+  else if (dtype == CRG_BF16)
+    hipLaunchKernelGGL(axpby_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16*)x, (bf16*)y, (long)n, a, b);
+  else
+    return crg_fail(ctx, -22, "axpby: dtype %d unsupported", dtype);
+  CRG_CHECK_LAUNCH(ctx, "axpby");
+  return 0;
+}

@@ -1,0 +1,276 @@
+"""SpatialTransformer / BasicTransformerBlock / CrossAttention / FeedForward on HIP kernels.
+
+Drop-in for modules/ldm/modules/attention.py: same constructor signatures (incl. `lora_ranks`,
+`lora_weights`, `ipa_scale`, `ipa_num_tokens`, attention.py:266-269,538-541,870-875,923-929), same
+parameter names (so SD1.5 checkpoints, the 792 LoRA keys of
+cremage/utils/sd15_weight_list_with_lora.py and `to_k_ipa/to_v_ipa` load unchanged), same
+`ATTENTION_MODES` registry (attention.py:865-869) with every mode mapped to the one HIP class.
+
+What differs is only HOW forward computes:
+  * tokens stay [B, HW, C] = the channels-last image itself: no `b c h w -> b (hw) c` copies
+    (attention.py:1045,1048);
+  * q/k/v/out, proj_in/out, GEGLU and net.2 are MFMA GEMMs with bias / residual / GEGLU fused in the
+    epilogue; V is produced already transposed for the flash kernel;
+  * softmax(QK^T)V is one flash-style kernel, never materialising the N x N scores;
+  * LoRA branches (attention.py:88-96,157-168,616-641,685-692,1038-1056) are folded into an
+    effective weight W + sum_i w_i (alpha_i / r_i) Up_i Down_i when the packed weight is (re)built;
+  * cross-attention K / V^T are cached while the very same context tensor object is passed again
+    (the context is step-invariant).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .nn import Conv2d, Linear, Normalize, zero_module
+
+
+def exists(v):
+    return v is not None
+
+
+def default(v, d):
+    return v if exists(v) else d
+
+
+def zero_init_module(module):
+    for p in module.parameters():
+        p.data.zero_()
+    return module
+
+
+# ---------------------------------------------------------------------------------------------- LoRA folding
+_merge_cache = {}
+
+
+def _tkey(t: torch.Tensor):
+    return (t.data_ptr(), t._version, t.dtype, t.device, tuple(t.shape))
+
+
+def effective_weight(base: torch.Tensor, downs, ups, alphas, ranks, weights) -> torch.Tensor:
+    """W + sum_i weights[i] * (alpha_i / rank_i) * Up_i @ Down_i  (fp32, cached on all operands).
+    Equals the reference's additive branch `d = up(down(x)); out += d * w * (alpha / rank)`."""
+    if not ranks:
+        return base
+    key = (_tkey(base),) + tuple((_tkey(d.weight), _tkey(u.weight), _tkey(a), float(w)) for d, u, a, w in zip(downs, ups, alphas, weights))
+    hit = _merge_cache.get(key)
+    if hit is not None:
+        return hit
+    if len(_merge_cache) > 2048:
+        _merge_cache.clear()
+    with torch.no_grad():
+        w = base.detach().float().reshape(base.shape[0], -1).clone()
+        for d, u, a, lw, r in zip(downs, ups, alphas, weights, ranks):
+            dn = d.weight.detach().float().reshape(d.weight.shape[0], -1)
+            up = u.weight.detach().float().reshape(u.weight.shape[0], -1)
+            w += (up @ dn) * (float(lw) * float(a.detach().float()) / float(r))
+        w = w.reshape(base.shape).contiguous()
+    _merge_cache[key] = w
+    return w
+
+
+def _lora_lists(obj, prefix: str, in_dim: int, out_dim: int, ranks, conv: bool = False):
+    downs, ups, alphas = nn.ModuleList(), nn.ModuleList(), nn.ParameterList()
+    for rank in ranks:
+        if conv:
+            downs.append(zero_init_module(nn.Conv2d(in_dim, rank, kernel_size=1, stride=1, padding=0, bias=False)))
+            ups.append(zero_init_module(nn.Conv2d(rank, out_dim, kernel_size=1, stride=1, padding=0, bias=False)))
+        else:
+            downs.append(zero_init_module(nn.Linear(in_dim, rank, bias=False)))
+            ups.append(zero_init_module(nn.Linear(rank, out_dim, bias=False)))
+        alphas.append(nn.Parameter(torch.tensor(float(rank))))
+    setattr(obj, prefix + "_lora_downs", downs)
+    setattr(obj, prefix + "_lora_ups", ups)
+    setattr(obj, prefix + "_lora_alphas", alphas)
+
+
+def _eff(obj, base: torch.Tensor, prefix: str) -> torch.Tensor:
+    return effective_weight(base, getattr(obj, prefix + "_lora_downs"), getattr(obj, prefix + "_lora_ups"),
+                            getattr(obj, prefix + "_lora_alphas"), obj.lora_ranks, obj.lora_weights)
+
+
+# ---------------------------------------------------------------------------------------------- feed-forward
+class GEGLU_with_lora(nn.Module):
+    """attention.py:66-96: proj Linear(dim_in -> 2*dim_out) [+LoRA], x * gelu(gate) (erf form)."""
+
+    def __init__(self, dim_in, dim_out, lora_ranks: List[int] = None, lora_weights: List[float] = None):
+        super().__init__()
+        self.lora_ranks = lora_ranks if lora_ranks is not None else []
+        self.lora_weights = lora_weights if lora_weights is not None else [1.0] * len(self.lora_ranks)
+        self.proj = Linear(dim_in, dim_out * 2)
+        _lora_lists(self, "proj", dim_in, dim_out * 2, self.lora_ranks)
+
+    def forward(self, x):
+        return ops.linear(x, _eff(self, self.proj.weight, "proj"), self.proj.bias, act="geglu")
+
+
+class FeedForward(nn.Module):
+    """attention.py:119-168 (glu=True is what SD uses, BasicTransformerBlock passes gated_ff=True)."""
+
+    def __init__(self, dim, dim_out=None, mult=4, glu=False, dropout=0., lora_ranks: List[int] = None,
+                 lora_weights: List[float] = None):
+        super().__init__()
+        self.lora_ranks = lora_ranks if lora_ranks is not None else []
+        self.lora_weights = lora_weights if lora_weights is not None else [1.0] * len(self.lora_ranks)
+        inner_dim = int(dim * mult)
+        dim_out = default(dim_out, dim)
+        if not glu:
+            raise NotImplementedError("FeedForward(glu=False) is not on the SD path (attention.py:135-137)")
+        if dropout != 0.:
+            raise NotImplementedError("inference-only: dropout must be 0")
+        self.net = nn.ModuleList([GEGLU_with_lora(dim, inner_dim, lora_ranks=lora_ranks, lora_weights=lora_weights),
+                                  nn.Dropout(dropout), Linear(inner_dim, dim_out)])
+        _lora_lists(self, "net_2", inner_dim, dim_out, self.lora_ranks)
+
+    def forward(self, x, residual=None):
+        h = self.net[0](x)
+        return ops.linear(h, _eff(self, self.net[2].weight, "net_2"), self.net[2].bias, residual=residual)
+
+
+# ---------------------------------------------------------------------------------------------- attention
+class CrossAttention(nn.Module):
+    """HIP counterpart of CrossAttentionOriginal / CrossAttention / MemoryEfficientCrossAttention
+    (attention.py:537-693, 265-534, 696-861): identical parameters, one flash-attention kernel."""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0., lora_ranks: List[int] = None,
+                 lora_weights: List[float] = None, ipa_scale=1.0, ipa_num_tokens=0):
+        super().__init__()
+        self.lora_ranks = lora_ranks if lora_ranks is not None else []
+        self.lora_weights = lora_weights if lora_weights is not None else [1.0] * len(self.lora_ranks)
+        self.ipa_scale = ipa_scale
+        self.ipa_num_tokens = ipa_num_tokens
+        inner_dim = dim_head * heads
+        context_dim = default(context_dim, query_dim)
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        self.to_q = Linear(query_dim, inner_dim, bias=False)
+        self.to_k = Linear(context_dim, inner_dim, bias=False)
+        self.to_v = Linear(context_dim, inner_dim, bias=False)
+        self.to_out = nn.Sequential(Linear(inner_dim, query_dim), nn.Dropout(dropout))
+        _lora_lists(self, "q", query_dim, inner_dim, self.lora_ranks)
+        _lora_lists(self, "k", context_dim, inner_dim, self.lora_ranks)
+        _lora_lists(self, "v", context_dim, inner_dim, self.lora_ranks)
+        _lora_lists(self, "out", inner_dim, query_dim, self.lora_ranks)
+        if self.ipa_num_tokens > 0:  # IP-Adapter FaceID, attention.py:606-609
+            self.to_k_ipa = Linear(context_dim, inner_dim, bias=False)
+            self.to_v_ipa = Linear(context_dim, inner_dim, bias=False)
+        self._kv = None  # (context tensor object, version, weight keys, k, vt, [k_ipa, vt_ipa])
+
+    def _project_kv(self, context: torch.Tensor, dtype: torch.dtype):
+        wk, wv = _eff(self, self.to_k.weight, "k"), _eff(self, self.to_v.weight, "v")
+        wkeys = (_tkey(wk), _tkey(wv), dtype)
+        c = self._kv
+        if c is not None and c[0] is context and c[1] == context._version and c[2] == wkeys:
+            return c[3]
+        ctx = context if context.dtype == dtype else context.to(dtype)
+        ipa = None
+        if self.ipa_num_tokens > 0:  # attention.py:623-627: last tokens go to the FaceID K/V projections
+            end = ctx.shape[1] - self.ipa_num_tokens
+            ctx, ipa_ctx = ctx[:, :end].contiguous(), ctx[:, end:].contiguous()
+            ipa = (ops.linear(ipa_ctx, self.to_k_ipa.weight), ops.linear_transposed(ipa_ctx, self.to_v_ipa.weight), ipa_ctx.shape[1])
+        out = (ops.linear(ctx, wk), ops.linear_transposed(ctx, wv), ctx.shape[1], ipa)
+        self._kv = (context, context._version, wkeys, out)
+        return out
+
+    def forward(self, x, context=None, mask=None, residual=None):
+        if exists(mask):
+            raise NotImplementedError("attention masks are never passed on the SD path (attention.py:648-652)")
+        q = ops.linear(x, _eff(self, self.to_q.weight, "q"))
+        if context is None:
+            k = ops.linear(x, _eff(self, self.to_k.weight, "k"))
+            vt = ops.linear_transposed(x, _eff(self, self.to_v.weight, "v"))
+            nk, ipa = x.shape[1], None
+            if self.ipa_num_tokens > 0:
+                raise NotImplementedError("ipa_num_tokens > 0 needs a context (attention.py:623-627)")
+        else:
+            k, vt, nk, ipa = self._project_kv(context, x.dtype)
+        out = ops.attention(q, k, vt, self.heads, nk, self.scale)
+        if ipa is not None:  # attention.py:660-681
+            out_ipa = ops.attention(q, ipa[0], ipa[1], self.heads, ipa[2], self.scale)
+            ops.axpby_(out, out_ipa, float(self.ipa_scale), 1.0)
+        return ops.linear(out, _eff(self, self.to_out[0].weight, "out"), self.to_out[0].bias, residual=residual)
+
+
+CrossAttentionOriginal = CrossAttention
+MemoryEfficientCrossAttention = CrossAttention
+
+
+class BasicTransformerBlock(nn.Module):
+    """attention.py:864-912.  All registry modes resolve to the HIP class; the reference's selection
+    logic (:877-883) only ever chose among numerically equivalent implementations."""
+    ATTENTION_MODES = {
+        "softmax": CrossAttention,
+        "softmax-xformers": CrossAttention,
+        "softmax-original": CrossAttention,
+        "softmax-hip": CrossAttention,
+    }
+
+    def __init__(self, dim, n_heads, d_head, dropout=0., context_dim=None, gated_ff=True, checkpoint=True,
+                 disable_self_attn=False, lora_ranks: List[int] = None, lora_weights: List[float] = None, ipa_scale=1.0,
+                 ipa_num_tokens=0):
+        super().__init__()
+        attn_cls = self.ATTENTION_MODES["softmax-hip"]
+        self.disable_self_attn = disable_self_attn
+        self.attn1 = attn_cls(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout,
+                              context_dim=context_dim if self.disable_self_attn else None, lora_ranks=lora_ranks,
+                              lora_weights=lora_weights)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff, lora_ranks=lora_ranks, lora_weights=lora_weights)
+        self.attn2 = attn_cls(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head, dropout=dropout,
+                              lora_ranks=lora_ranks, lora_weights=lora_weights, ipa_scale=ipa_scale, ipa_num_tokens=ipa_num_tokens)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.checkpoint = checkpoint  # gradient checkpointing is a no-op at inference (util.py:102-116)
+
+    @staticmethod
+    def _ln(norm: nn.LayerNorm, x):
+        return ops.layer_norm(x, norm.weight, norm.bias, norm.eps)
+
+    def forward(self, x, context=None):
+        return self._forward(x, context)
+
+    def _forward(self, x, context=None):
+        x = self.attn1(self._ln(self.norm1, x), context=context if self.disable_self_attn else None, residual=x)
+        x = self.attn2(self._ln(self.norm2, x), context=context, residual=x)
+        x = self.ff(self._ln(self.norm3, x), residual=x)
+        return x
+
+
+class SpatialTransformer(nn.Module):
+    """attention.py:915-1057.  `use_linear` is accepted and, as in the reference (:930-945), ignored:
+    proj_in/proj_out stay 1x1 Conv2d parameters so LoRA weights keep their shapes."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0., context_dim=None, disable_self_attn=False,
+                 use_linear=False, use_checkpoint=True, lora_ranks: List[int] = None, lora_weights: List[float] = None,
+                 ipa_scale=1.0, ipa_num_tokens=0):
+        super().__init__()
+        if exists(context_dim) and not isinstance(context_dim, list):
+            context_dim = [context_dim]
+        self.in_channels = in_channels
+        inner_dim = n_heads * d_head
+        self.norm = Normalize(in_channels)
+        self.lora_ranks = lora_ranks if lora_ranks is not None else []
+        self.lora_weights = lora_weights if lora_weights is not None else [1.0] * len(self.lora_ranks)
+        self.proj_in = Conv2d(in_channels, inner_dim, kernel_size=1, stride=1, padding=0)
+        _lora_lists(self, "proj_in", in_channels, inner_dim, self.lora_ranks, conv=True)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner_dim, n_heads, d_head, dropout=dropout, context_dim=context_dim[d],
+                                  disable_self_attn=disable_self_attn, checkpoint=use_checkpoint, lora_ranks=self.lora_ranks,
+                                  lora_weights=self.lora_weights, ipa_scale=ipa_scale, ipa_num_tokens=ipa_num_tokens)
+            for d in range(depth)])
+        self.proj_out = zero_module(Conv2d(inner_dim, in_channels, kernel_size=1, stride=1, padding=0))
+        _lora_lists(self, "proj_out", inner_dim, in_channels, self.lora_ranks, conv=True)
+
+    def forward(self, x, context=None):
+        x = ops.to_channels_last(x)
+        b, c, h, w = x.shape
+        x_in = ops.tokens_of(x)
+        xn = self.norm(x)
+        t = ops.linear(ops.tokens_of(xn), _eff(self, self.proj_in.weight, "proj_in"), self.proj_in.bias)
+        for block in self.transformer_blocks:
+            t = block(t, context=context)
+        y = ops.linear(t, _eff(self, self.proj_out.weight, "proj_out"), self.proj_out.bias, residual=x_in)
+        return ops.image_of(y, h, w)

@@ -1,0 +1,473 @@
+"""Torch-facing wrappers over the C-ABI (libcrg_hip.so).
+
+PyTorch is used here only as the allocator / stream owner (`torch.empty`, `data_ptr()`,
+`torch.cuda.current_stream()`); every arithmetic op on the hot path is a hand-written HIP kernel
+reached through `cremage_amd._lib`.  There is deliberately no CPU or eager fallback: a CPU tensor,
+an unsupported shape or a missing library raises.
+
+Layout contract: image activations are 4-D tensors with logical shape [N, C, H, W] and
+`torch.channels_last` strides (physically NHWC), so the reference's hooks that index channels on
+dim 1 (ControlNet residual adds cldm.py:57-65, `th.cat(..., dim=1)` openaimodel.py:808) keep
+working on them; token activations are contiguous [B, T, C].
+
+Precision contract: bf16 activations -> CRG_PREC_BF16 kernels; fp32 activations -> CRG_PREC_BF16X3
+(split-bf16, fp32-class) kernels.  Weights stay torch Parameters (any float dtype); their packed
+bf16 images are cached keyed on (data_ptr, _version, dtype, device, kind) so that
+`load_state_dict`, LoRA `setattr` (image_generator.py:408-453) and `.to()/.half()` invalidate them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.bfloat16: L.BF16, torch.float32: L.F32, torch.float16: L.F16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise L.CrgError(f"unsupported dtype {t.dtype}")
+
+
+def _act_dt(t: torch.Tensor) -> int:
+    if t.dtype not in (torch.bfloat16, torch.float32):
+        raise L.CrgError(f"activations must be bfloat16 or float32, got {t.dtype}")
+    return _DT[t.dtype]
+
+
+def _prec(t: torch.Tensor) -> int:
+    return L.PREC_BF16 if t.dtype == torch.bfloat16 else L.PREC_BF16X3
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.CrgError("cremage_amd.ops: tensors must live on a HIP device (no CPU fallback exists)")
+
+
+def _h(t: torch.Tensor):
+    return L.ctx(t.device.index if t.device.index is not None else torch.cuda.current_device())
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+# ---------------------------------------------------------------------------------- weight cache
+_pack_cache = {}
+_f32_cache = {}
+_PACK_CACHE_MAX = 4096
+
+
+def clear_weight_cache():
+    _pack_cache.clear()
+    _f32_cache.clear()
+
+
+def _key(w: torch.Tensor, *extra):
+    return (w.data_ptr(), w._version, w.dtype, w.device, tuple(w.shape), *extra)
+
+
+def f32_vec(v: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """fp32 contiguous view/copy of a bias / norm gain (kernels take fp32 vectors)."""
+    if v is None:
+        return None
+    if v.dtype == torch.float32 and v.is_contiguous():
+        return v.detach()
+    k = _key(v)
+    r = _f32_cache.get(k)
+    if r is None:
+        if len(_f32_cache) > _PACK_CACHE_MAX:
+            _f32_cache.clear()
+        r = v.detach().float().contiguous()
+        _f32_cache[k] = r
+    return r
+
+
+def packed_weight(w: torch.Tensor, kind: int, split: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """bf16 [N, K] image of a Linear / conv weight (+ bf16 residual plane when `split`)."""
+    _need_cuda(w)
+    if kind == L.PACK_LINEAR and not split and w.dtype == torch.bfloat16 and w.is_contiguous():
+        return w.detach().reshape(w.shape[0], -1), None  # zero-copy: already the packed image
+    k = _key(w, kind, split)
+    r = _pack_cache.get(k)
+    if r is not None:
+        return r
+    if len(_pack_cache) > _PACK_CACHE_MAX:
+        _pack_cache.clear()
+    src = w.detach().contiguous()
+    n_out = src.shape[0]
+    if kind == L.PACK_CONV:
+        n_in, ks = src.shape[1], src.shape[2]
+        cols = n_in * ks * ks
+    else:
+        n_in, ks = src[0].numel(), 1
+        cols = n_in
+    hi = torch.empty((n_out, cols), dtype=torch.bfloat16, device=w.device)
+    lo = torch.empty_like(hi) if split else None
+    h = _h(w)
+    L.check(L.load().crg_pack_weight(h, _st(), _p(src), _dt(src), kind, n_out, n_in, ks, _p(hi), _p(lo)), h, "crg_pack_weight")
+    _pack_cache[k] = (hi, lo)
+    return hi, lo
+
+
+def packed_geglu_bias(b: torch.Tensor) -> torch.Tensor:
+    k = _key(b, "geglu_bias")
+    r = _pack_cache.get(k)
+    if r is None:
+        src = b.detach().float().contiguous()
+        r = torch.empty_like(src)
+        h = _h(b)
+        L.check(L.load().crg_pack_geglu_bias(h, _st(), _p(src), src.numel(), _p(r)), h, "crg_pack_geglu_bias")
+        _pack_cache[k] = r
+    return r
+
+
+# ---------------------------------------------------------------------------------- layout helpers
+def to_channels_last(x: torch.Tensor) -> torch.Tensor:
+    """No-op for tensors that already have NHWC strides; otherwise one boundary transpose kernel."""
+    if x.dim() != 4:
+        raise L.CrgError(f"expected a 4-D image tensor, got shape {tuple(x.shape)}")
+    if x.permute(0, 2, 3, 1).is_contiguous():
+        return x
+    return nchw_to_nhwc(x.contiguous(), x.dtype)
+
+
+def empty_image(n, c, h, w, dtype, device) -> torch.Tensor:
+    return torch.empty((n, h, w, c), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+def tokens_of(x: torch.Tensor) -> torch.Tensor:
+    """[N, C, H, W] channels-last image -> [N, H*W, C] contiguous view (no copy)."""
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n, h * w, c)
+
+
+def image_of(t: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """[N, H*W, C] tokens -> [N, C, H, W] channels-last view (no copy)."""
+    n, hw, c = t.shape
+    return t.reshape(n, h, w, c).permute(0, 3, 1, 2)
+
+
+def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Contiguous NCHW tensor -> channels-last tensor of `dtype` (one transpose+cast kernel)."""
+    _need_cuda(x)
+    n, c, hh, ww = x.shape
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    x = x.contiguous()
+    y = empty_image(n, c, hh, ww, dtype, x.device)
+    h = _h(x)
+    L.check(L.load().crg_nchw_to_nhwc(h, _st(), _p(x), _p(y), n, c, hh * ww, _act_dt(x), _DT[dtype]), h, "crg_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Channels-last tensor -> contiguous NCHW tensor of `dtype`."""
+    _need_cuda(x)
+    x = to_channels_last(x)
+    n, c, hh, ww = x.shape
+    y = torch.empty((n, c, hh, ww), dtype=dtype, device=x.device)
+    h = _h(x)
+    L.check(L.load().crg_nhwc_to_nchw(h, _st(), _p(x), _p(y), n, c, hh * ww, _act_dt(x), _DT[dtype]), h, "crg_nhwc_to_nchw")
+    return y
+
+
+def affine_cast(x: torch.Tensor, a: float, b: float, dtype: torch.dtype, lo: float = float("-inf"), hi: float = float("inf")):
+    """y = clamp(a*x + b, lo, hi) cast to `dtype`, preserving strides (dense tensors only)."""
+    _need_cuda(x)
+    y = torch.empty_strided(x.shape, x.stride(), dtype=dtype, device=x.device)
+    h = _h(x)
+    L.check(L.load().crg_affine_cast(h, _st(), _p(x), _p(y), x.numel(), a, b, lo, hi, _act_dt(x), _DT[dtype]), h, "crg_affine_cast")
+    return y
+
+
+# ---------------------------------------------------------------------------------- norms
+def group_norm(x: torch.Tensor, weight, bias, groups: int, eps: float, silu: bool = False, x2: Optional[torch.Tensor] = None):
+    """GroupNorm(+SiLU) over a channels-last image; `x2` = second half of a virtual channel concat."""
+    _need_cuda(x, weight, bias, x2)
+    x = to_channels_last(x)
+    n, c1, hh, ww = x.shape
+    c = c1
+    if x2 is not None:
+        x2 = to_channels_last(x2)
+        if x2.shape[0] != n or x2.shape[2:] != x.shape[2:] or x2.dtype != x.dtype:
+            raise L.CrgError("group_norm: concat halves disagree in shape/dtype")
+        c = c1 + x2.shape[1]
+    if weight.numel() != c:
+        raise L.CrgError(f"group_norm: {weight.numel()} gains for {c} channels")
+    y = empty_image(n, c, hh, ww, x.dtype, x.device)
+    h = _h(x)
+    L.check(L.load().crg_groupnorm(h, _st(), _p(x), _p(x2), c1, _p(f32_vec(weight)), _p(f32_vec(bias)), _p(y), n, hh * ww, c,
+                                   groups, eps, int(silu), _act_dt(x)), h, "crg_groupnorm")
+    return y
+
+
+def layer_norm(x: torch.Tensor, weight, bias, eps: float = 1e-5):
+    _need_cuda(x, weight, bias)
+    x = x.contiguous()
+    dim = x.shape[-1]
+    y = torch.empty_like(x)
+    h = _h(x)
+    L.check(L.load().crg_layernorm(h, _st(), _p(x), _p(f32_vec(weight)), _p(f32_vec(bias)), _p(y), x.numel() // dim, dim, eps,
+                                   _act_dt(x)), h, "crg_layernorm")
+    return y
+
+
+def softmax_rows_(x: torch.Tensor, cols: int, scale: float):
+    """In-place softmax(x[:, :cols] * scale) over the last dim of a 2-D view with row stride x.shape[-1]."""
+    _need_cuda(x)
+    ld = x.shape[-1]
+    rows = x.numel() // ld
+    h = _h(x)
+    L.check(L.load().crg_softmax_rows(h, _st(), _p(x), _p(x), rows, cols, ld, scale, _act_dt(x)), h, "crg_softmax_rows")
+    return x
+
+
+# ---------------------------------------------------------------------------------- GEMM family
+def _gemm(h, **kw):
+    a = L.GemmArgs()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    L.check(L.load().crg_gemm(h, _st(), C.byref(a)), h, "crg_gemm")
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+           act: Optional[str] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """y = act(x @ weight^T + bias) + residual over the last dim of x.
+    weight: [N, K] (nn.Linear) or [N, K, 1, 1] (1x1 conv).  act: None | 'silu' | 'geglu'."""
+    _need_cuda(x, weight, bias, residual)
+    x = x.contiguous()
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = weight.shape[0]
+    if weight[0].numel() != K:
+        raise L.CrgError(f"linear: weight {tuple(weight.shape)} does not match input width {K}")
+    split = x.dtype == torch.float32
+    out_dtype = out_dtype or x.dtype
+    if split and out_dtype != torch.float32:
+        raise L.CrgError("linear: fp32 (BF16X3) inputs produce fp32 outputs")
+    geglu = act == "geglu"
+    hi, lo = packed_weight(weight, L.PACK_GEGLU if geglu else L.PACK_LINEAR, split)
+    n_out = N // 2 if geglu else N
+    y = torch.empty(x.shape[:-1] + (n_out,), dtype=out_dtype, device=x.device)
+    b = None
+    if bias is not None:
+        b = packed_geglu_bias(bias) if geglu else f32_vec(bias)
+    if residual is not None:
+        residual = residual.contiguous()
+        if residual.shape != y.shape or residual.dtype != y.dtype:
+            raise L.CrgError("linear: residual must match the output in shape and dtype")
+    h = _h(x)
+    _gemm(h, a=x.data_ptr(), lda=K, a_bstride=0, w=hi.data_ptr(), ldw=K, w_bstride=0, w_lo=lo.data_ptr() if lo is not None else None,
+          bias=b.data_ptr() if b is not None else None, bias_mode=L.BIAS_COL if b is not None else L.BIAS_NONE,
+          residual=residual.data_ptr() if residual is not None else None, ldr=n_out, r_bstride=0,
+          y=y.data_ptr(), ldy=n_out, y_bstride=0, M=M, N=N, K=K, batch=1,
+          epilogue={None: L.EPI_NONE, "silu": L.EPI_SILU, "geglu": L.EPI_GEGLU}[act],
+          a_dtype=_act_dt(x), y_dtype=_DT[out_dtype], prec=_prec(x), a_is_weight=0, a_lo=None)
+    return y
+
+
+def linear_transposed(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b] = weight @ x[b]^T (+ bias per row): [B, T, K] tokens -> [B, N, ld] with ld = roundup(T, 8).
+    Emits the V projection already transposed ([channel][key]) for crg_attention; pad columns are
+    never read unmasked (the kernel masks keys >= T)."""
+    _need_cuda(x, weight, bias)
+    x = x.contiguous()
+    B, T, K = x.shape
+    N = weight.shape[0]
+    split = x.dtype == torch.float32
+    hi, lo = packed_weight(weight, L.PACK_LINEAR, split)
+    ld = (T + 7) // 8 * 8
+    y = torch.empty((B, N, ld), dtype=x.dtype, device=x.device)
+    if ld != T:
+        y[:, :, T:].zero_()
+    b = f32_vec(bias)
+    h = _h(x)
+    if not split:
+        # A := weight (bf16 packed), W := activations (bf16 rows are already the "packed" layout)
+        _gemm(h, a=hi.data_ptr(), lda=K, a_bstride=0, w=x.data_ptr(), ldw=K, w_bstride=T * K, w_lo=None,
+              bias=b.data_ptr() if b is not None else None, bias_mode=L.BIAS_ROW if b is not None else L.BIAS_NONE,
+              residual=None, ldr=0, r_bstride=0, y=y.data_ptr(), ldy=ld, y_bstride=N * ld, M=N, N=T, K=K, batch=B,
+              epilogue=L.EPI_NONE, a_dtype=L.BF16, y_dtype=L.BF16, prec=L.PREC_BF16, a_is_weight=1, a_lo=None)
+    else:
+        # fp32 activations cannot sit on the pre-split W side: split them once on the fly
+        xh = x.to(torch.bfloat16)
+        xl = (x - xh.float()).to(torch.bfloat16)
+        _gemm(h, a=hi.data_ptr(), lda=K, a_bstride=0, a_lo=lo.data_ptr(), w=xh.data_ptr(), w_lo=xl.data_ptr(), ldw=K,
+              w_bstride=T * K, bias=b.data_ptr() if b is not None else None,
+              bias_mode=L.BIAS_ROW if b is not None else L.BIAS_NONE, residual=None, ldr=0, r_bstride=0, y=y.data_ptr(), ldy=ld,
+              y_bstride=N * ld, M=N, N=T, K=K, batch=B, epilogue=L.EPI_NONE, a_dtype=L.BF16, y_dtype=L.F32,
+              prec=L.PREC_BF16X3, a_is_weight=1)
+    return y
+
+
+# ---------------------------------------------------------------------------------- conv
+def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, padding=1,
+           upsample2x: bool = False, x2: Optional[torch.Tensor] = None, cvec: Optional[torch.Tensor] = None,
+           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Implicit-GEMM conv over channels-last images.
+    padding: int (symmetric) or (top, left, bottom, right).  `upsample2x`: nearest-2x of the input is
+    folded into the gather.  `x2`: second half of a virtual channel concat.  `cvec` fp32 [N, Cout] is
+    added per sample (timestep embedding); `residual` is added after."""
+    _need_cuda(x, weight, bias, x2, cvec, residual)
+    x = to_channels_last(x)
+    n, c1, hh, ww = x.shape
+    c2 = 0
+    if x2 is not None:
+        x2 = to_channels_last(x2)
+        c2 = x2.shape[1]
+        if x2.shape[0] != n or x2.shape[2:] != x.shape[2:] or x2.dtype != x.dtype:
+            raise L.CrgError("conv2d: concat halves disagree in shape/dtype")
+    cout, cin, ks, _ = weight.shape
+    if cin != c1 + c2:
+        raise L.CrgError(f"conv2d: weight expects {cin} input channels, got {c1}+{c2}")
+    if isinstance(padding, int):
+        pt = pl = pb = pr = padding
+    else:
+        pt, pl, pb, pr = padding
+    hv, wv = (2 * hh, 2 * ww) if upsample2x else (hh, ww)
+    ho = (hv + pt + pb - ks) // stride + 1
+    wo = (wv + pl + pr - ks) // stride + 1
+    if cin <= 8 or cout <= 8:
+        if stride != 1 or upsample2x or x2 is not None or cvec is not None or residual is not None or (pt, pl, pb, pr) != (ks // 2,) * 4:
+            raise L.CrgError("conv2d: thin-channel convs support only stride 1, 'same' padding, no fusions")
+        y = empty_image(n, cout, ho, wo, x.dtype, x.device)
+        w32 = f32_vec(weight)
+        h = _h(x)
+        L.check(L.load().crg_conv_small(h, _st(), _p(x), _p(w32), _p(f32_vec(bias)), _p(y), n, hh, ww, cin, cout, ks, _act_dt(x),
+                                        _act_dt(y)), h, "crg_conv_small")
+        return y
+    split = x.dtype == torch.float32
+    hi, lo = packed_weight(weight, L.PACK_CONV, split)
+    y = empty_image(n, cout, ho, wo, x.dtype, x.device)
+    if residual is not None:
+        residual = to_channels_last(residual)
+        if residual.shape != y.shape or residual.dtype != y.dtype:
+            raise L.CrgError("conv2d: residual must match the output in shape and dtype")
+    if cvec is not None:
+        if cvec.dtype != torch.float32 or tuple(cvec.shape) != (n, cout):
+            raise L.CrgError("conv2d: cvec must be fp32 [N, Cout]")
+        cvec = cvec.contiguous()
+    a = L.ConvArgs(x=x.data_ptr(), x2=x2.data_ptr() if x2 is not None else None, C1=c1, C2=c2, w=hi.data_ptr(),
+                   w_lo=lo.data_ptr() if lo is not None else None, bias=_p(f32_vec(bias)).value, cvec=_p(cvec).value,
+                   residual=_p(residual).value, y=y.data_ptr(), N=n, H=hh, W=ww, Cout=cout, Ho=ho, Wo=wo, ksize=ks, stride=stride,
+                   pad_t=pt, pad_l=pl, upsample2x=int(upsample2x), x_dtype=_act_dt(x), y_dtype=_act_dt(y), prec=_prec(x))
+    h = _h(x)
+    L.check(L.load().crg_conv2d(h, _st(), C.byref(a)), h, "crg_conv2d")
+    return y
+
+
+def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias=None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """1x1 conv on a channels-last image == linear over its token view (no copy either way)."""
+    x = to_channels_last(x)
+    n, c, hh, ww = x.shape
+    res_t = tokens_of(to_channels_last(residual)) if residual is not None else None
+    y = linear(tokens_of(x), weight, bias, residual=res_t)
+    return image_of(y, hh, ww)
+
+
+# ---------------------------------------------------------------------------------- attention
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, n_keys: int, scale: float) -> torch.Tensor:
+    """softmax(Q K^T * scale) V with heads split along the channel dim.
+    q: [B, Nq, C], k: [B, Nk, C], vt: [B, C, ld] (V transposed, ld = roundup(Nk, 8)) -> [B, Nq, C]."""
+    _need_cuda(q, k, vt)
+    B, Nq, Cc = q.shape
+    Dh = Cc // heads
+    ld = vt.shape[-1]
+    h = _h(q)
+    if q.dtype == torch.bfloat16 and Dh <= 160:
+        o = torch.empty_like(q)
+        L.check(L.load().crg_attention(h, _st(), _p(q), Cc, _p(k), Cc, _p(vt), ld, _p(o), Cc, B, heads, Nq, n_keys, Dh, scale,
+                                       L.BF16), h, "crg_attention")
+        return o
+    # Unfused path: S = QK^T (fp32) -> row softmax -> PV, all on the GEMM kernels.  Serves the fp32-class
+    # (BF16X3) configuration and head dims beyond the flash kernel (the VAE's single-head C=512
+    # AttnBlock, model.py:185-209).
+    split = q.dtype == torch.float32
+    o = torch.empty_like(q)
+    kp = (n_keys + 7) // 8 * 8
+    s = torch.empty((heads, Nq, kp), dtype=torch.float32, device=q.device)
+    if kp != n_keys:
+        s[:, :, n_keys:].zero_()
+    for b in range(B):
+        kb, vb = k[b], vt[b]
+        if split:
+            kh = kb.to(torch.bfloat16)
+            kl = (kb - kh.float()).to(torch.bfloat16)
+            vh = vb.to(torch.bfloat16)
+            vl = (vb - vh.float()).to(torch.bfloat16)
+        else:
+            kh, kl, vh, vl = kb, None, vb, None
+        prec = L.PREC_BF16X3 if split else L.PREC_BF16
+        _gemm(h, a=q[b].data_ptr(), lda=Cc, a_bstride=Dh, w=kh.data_ptr(), w_lo=kl.data_ptr() if split else None, ldw=Cc,
+              w_bstride=Dh, bias=None, bias_mode=L.BIAS_NONE, residual=None, ldr=0, r_bstride=0, y=s.data_ptr(), ldy=kp,
+              y_bstride=Nq * kp, M=Nq, N=n_keys, K=Dh, batch=heads, epilogue=L.EPI_NONE, a_dtype=_act_dt(q), y_dtype=L.F32,
+              prec=prec, a_is_weight=0, a_lo=None)
+        softmax_rows_(s, n_keys, scale)
+        _gemm(h, a=s.data_ptr(), lda=kp, a_bstride=Nq * kp, w=vh.data_ptr(), w_lo=vl.data_ptr() if split else None, ldw=ld,
+              w_bstride=Dh * ld, bias=None, bias_mode=L.BIAS_NONE, residual=None, ldr=0, r_bstride=0, y=o[b].data_ptr(), ldy=Cc,
+              y_bstride=Dh, M=Nq, N=Dh, K=kp, batch=heads, epilogue=L.EPI_NONE, a_dtype=L.F32, y_dtype=_act_dt(q), prec=prec,
+              a_is_weight=0, a_lo=None)
+    return o
+
+
+# ---------------------------------------------------------------------------------- small ops
+def timestep_embedding(t: torch.Tensor, dim: int, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    _need_cuda(t)
+    t = t.detach().float().contiguous()
+    y = torch.empty((t.shape[0], dim), dtype=dtype, device=t.device)
+    h = _h(t)
+    L.check(L.load().crg_timestep_embedding(h, _st(), _p(t), _p(y), t.shape[0], dim, _DT[dtype]), h, "crg_timestep_embedding")
+    return y
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    _need_cuda(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    h = _h(x)
+    L.check(L.load().crg_silu(h, _st(), _p(x), _p(y), x.numel(), _act_dt(x)), h, "crg_silu")
+    return y
+
+
+def axpby_(y: torch.Tensor, x: torch.Tensor, a: float, b: float = 1.0) -> torch.Tensor:
+    """In place y = a*x + b*y (same dense layout on both sides)."""
+    _need_cuda(x, y)
+    if x.shape != y.shape or x.stride() != y.stride() or x.dtype != y.dtype:
+        raise L.CrgError("axpby_: operands must agree in shape, strides and dtype")
+    h = _h(x)
+    L.check(L.load().crg_axpby(h, _st(), _p(x), _p(y), x.numel(), a, b, _act_dt(x)), h, "crg_axpby")
+    return y
+
+
+# ---------------------------------------------------------------------------------- profiling
+class profile:
+    """Context manager: per-kernel-family device time (HIP events on the launch stream) + algorithmic
+    FLOPs/bytes of every crg_* launch issued inside it (bench.py's `roofline`)."""
+
+    def __init__(self, device=None):
+        self.dev = torch.cuda.current_device() if device is None else device
+        self.result = None
+
+    def __enter__(self):
+        h = L.ctx(self.dev)
+        L.check(L.load().crg_profile_begin(h), h, "crg_profile_begin")
+        return self
+
+    def __exit__(self, *exc):
+        h = L.ctx(self.dev)
+        p = L.Profile()
+        L.check(L.load().crg_profile_end(h, _st(), C.byref(p)), h, "crg_profile_end")
+        self.result = {L.FAMILY_NAMES[i]: dict(ms=p.ms[i], flops=p.flops[i], bytes=p.bytes[i], launches=p.launches[i])
+                       for i in range(L.K_FAMILIES)}
+        return False

@@ -1,0 +1,196 @@
+/*
+ * crg_hip.h - C-ABI of libcrg_hip.so: hand-written HIP/CDNA4 (gfx950) kernels for the
+ * Stable Diffusion denoising path of HowToSD/cremage (UNet step + VAE decode/encode).
+ *
+ * The reference has NO native FFI: its "kernels" are PyTorch call sites inside the L6
+ * compute modules.  Each entry point below replaces one family
+ * of those call sites; the reference interface it replaces is cited per function
+ * (paths relative to the reference root).  The Python binding a maintainer adds is
+ * cremage_amd/_lib.py (ctypes); see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a raw DEVICE pointer (tensor.data_ptr()), caller-owned;
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream);
+ *   - activations are channels-last: images [N][H][W][C] ("NHWC"), tokens [B][T][C];
+ *   - all kernels are asynchronous on `stream`; no call synchronises, allocates or frees
+ *     (graph-capture safe) except crg_ctx_create/destroy/reserve;
+ *   - return value: 0 = ok, negative = error; text via crg_last_error(ctx).  The library
+ *     never aborts (the reference's ML process has no handler, mp/mp.py:125).
+ *   - one context per device, not re-entrant (the reference is single-threaded,
+ *     mp/mp.py:32-127).
+ */
+#ifndef CRG_HIP_H
+#define CRG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRG_VERSION 100
+
+typedef struct crg_ctx crg_ctx;
+
+enum crg_dtype { CRG_BF16 = 0, CRG_F32 = 1, CRG_F16 = 2 };
+
+/* GEMM/conv arithmetic:
+ *   CRG_PREC_BF16   operands rounded to bf16, one MFMA pass, fp32 accumulate;
+ *   CRG_PREC_BF16X3 operands split hi+lo bf16, three MFMA passes (hi*hi + hi*lo + lo*hi),
+ *                   fp32 accumulate: ~2^-17 relative operand error ("fp32-class"), used for
+ *                   the VAE (pixel L-inf <= 1e-3 target) and the fp32 parity configuration. */
+enum crg_prec { CRG_PREC_BF16 = 0, CRG_PREC_BF16X3 = 1 };
+
+enum crg_epilogue {
+  CRG_EPI_NONE = 0,
+  CRG_EPI_SILU = 1,  /* y = silu(acc + bias)                                  */
+  CRG_EPI_GEGLU = 2  /* y[:, j] = (acc_v + b_v) * gelu_erf(acc_g + b_g); W packed with crg_pack_geglu */
+};
+
+enum crg_bias_mode { CRG_BIAS_NONE = 0, CRG_BIAS_COL = 1 /* bias[n] */, CRG_BIAS_ROW = 2 /* bias[m] */ };
+
+/* ---- context ------------------------------------------------------------------------- */
+int crg_version(void);
+int crg_ctx_create(int device, crg_ctx** out);
+void crg_ctx_destroy(crg_ctx* ctx);
+const char* crg_last_error(crg_ctx* ctx);
+/* Pre-size the context's scratch (GroupNorm partial statistics, split-K slabs). Synchronous. */
+int crg_ctx_reserve(crg_ctx* ctx, size_t bytes);
+
+/* ---- per-kernel timing (bench.py roofline: HIP events on the launch stream) ------------ */
+/* Between begin/end every crg_* launch is bracketed by hipEvents and tagged with its kernel
+ * family and algorithmic FLOPs/bytes.  crg_profile_end synchronises and fills `out`. */
+enum crg_kernel_family {
+  CRG_K_GEMM = 0, CRG_K_CONV = 1, CRG_K_ATTN = 2, CRG_K_GROUPNORM = 3, CRG_K_LAYERNORM = 4,
+  CRG_K_ELEMENTWISE = 5, CRG_K_CONV_SMALL = 6, CRG_K_SOFTMAX = 7, CRG_K_FAMILIES = 8
+};
+typedef struct {
+  double ms[CRG_K_FAMILIES];     /* summed device time per family               */
+  double flops[CRG_K_FAMILIES];  /* summed algorithmic FLOPs (2*MAC)            */
+  double bytes[CRG_K_FAMILIES];  /* summed algorithmic (minimum) HBM bytes      */
+  int64_t launches[CRG_K_FAMILIES];
+} crg_profile;
+int crg_profile_begin(crg_ctx* ctx);
+int crg_profile_end(crg_ctx* ctx, void* stream, crg_profile* out);
+
+/* ---- GroupNorm (+SiLU) ------------------------------------------------------------------
+ * Replaces GroupNorm32.forward (modules/ldm/modules/diffusionmodules/util.py:214-216, eps 1e-5,
+ * fp32 statistics) + nn.SiLU (openaimodel.py:207,231,754), Normalize (attention.py:189-190,
+ * model.py:45-46, eps 1e-6) + `nonlinearity` (model.py:40-42).
+ * x,y: [N][HW][C] of `dtype`; gamma,beta: fp32 [C].  Statistics and affine in fp32.
+ * If x2 != NULL the input is the virtual channel concat [x | x2] with C = C1 + C2
+ * (th.cat([h, hs.pop()], dim=1), openaimodel.py:808) and C1 % (C/groups) == 0. */
+int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* gamma,
+                  const float* beta, void* y, int N, int HW, int C, int groups, float eps, int fuse_silu,
+                  int dtype);
+
+/* ---- LayerNorm --------------------------------------------------------------------------
+ * Replaces nn.LayerNorm(dim) in BasicTransformerBlock (attention.py:900-902,909-911).
+ * x,y: [rows][dim] of `dtype`; gamma,beta fp32 [dim]. */
+int crg_layernorm(crg_ctx* ctx, void* stream, const void* x, const float* gamma, const float* beta, void* y,
+                  int64_t rows, int dim, float eps, int dtype);
+
+/* ---- GEMM: Y[b] = epi(A[b] (MxK) * W[b]^T (NxK) + bias) + residual ------------------------
+ * Replaces F.linear / 1x1 nn.Conv2d call sites: to_q/to_k/to_v (attention.py:614,629,636),
+ * to_out (:685), GEGLU proj + net[2] (:88-96,157-168), proj_in/proj_out (:1036,1049),
+ * time_embed / emb_layers (openaimodel.py:538-543,222-228), skip_connection 1x1 (:245),
+ * VAE q/k/v/proj_out/nin_shortcut (model.py:163-182,122-126), quant/post_quant_conv
+ * (autoencoder.py:302-303).  Both operands are K-contiguous ("NT").
+ *   a: `a_dtype` [M][lda];  w: packed by crg_pack_weight (bf16 planes) [N][ldw];
+ *   bias fp32; residual/y: `y_dtype`;  cvec fp32 [M / rows_per_cvec][N] added per row group.
+ * Swapping the roles of a and w yields transposed outputs (used to emit V^T for attention). */
+typedef struct {
+  const void* a; int64_t lda; int64_t a_bstride;
+  const void* w; int64_t ldw; int64_t w_bstride;   /* hi plane                      */
+  const void* w_lo;                                 /* lo plane (BF16X3) or NULL     */
+  const float* bias; int bias_mode;
+  const void* residual; int64_t ldr; int64_t r_bstride;
+  void* y; int64_t ldy; int64_t y_bstride;
+  int M, N, K, batch;
+  int epilogue;
+  int a_dtype, y_dtype, prec;
+  int a_is_weight;   /* BF16X3 only: `a` is a packed weight (hi plane) and a_lo its lo plane */
+  const void* a_lo;
+} crg_gemm_args;
+int crg_gemm(crg_ctx* ctx, void* stream, const crg_gemm_args* args);
+
+/* ---- conv2d as implicit GEMM ---------------------------------------------------------------
+ * Replaces conv_nd(2, Cin, Cout, 3, padding=1) (openaimodel.py:208,234,551,755), stride-2
+ * Downsample (:155-157), Upsample = nearest-2x + conv (:120-122; VAE model.py:60-64), the VAE
+ * convs (model.py:99-113,494-498,536-540) and its asymmetric-pad stride-2 Downsample
+ * (model.py:79-83, pad (0,1,0,1)).  Fused: skip concat as a second input pointer
+ * (openaimodel.py:808), nearest-2x upsample in the gather, bias, per-sample channel vector
+ * (the timestep-embedding add, openaimodel.py:268-277) and residual add (:279).
+ *   x: [N][H][W][C1] (+ x2: [N][H][W][C2]) of `x_dtype`; w: packed [Cout][kh*kw*(C1+C2)];
+ *   y/residual: [N][Ho][Wo][Cout] of `y_dtype`; cvec fp32 [N][Cout]; bias fp32 [Cout]. */
+typedef struct {
+  const void* x; const void* x2; int C1, C2;
+  const void* w; const void* w_lo;
+  const float* bias; const float* cvec;
+  const void* residual;
+  void* y;
+  int N, H, W, Cout, Ho, Wo;
+  int ksize, stride, pad_t, pad_l;  /* pad_b / pad_r are implied by Ho/Wo */
+  int upsample2x;
+  int x_dtype, y_dtype, prec;
+} crg_conv_args;
+int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* args);
+
+/* ---- weight packing -------------------------------------------------------------------------
+ * src: a torch parameter as the checkpoint stores it (fp32/bf16/fp16):
+ *   CRG_PACK_LINEAR   [N][K]            -> [N][K]             (nn.Linear / 1x1 conv)
+ *   CRG_PACK_CONV     [Cout][Cin][k][k] -> [Cout][k*k*Cin]    (tap-major, channel-minor)
+ *   CRG_PACK_GEGLU    [2*F][K]          -> rows interleaved in 16-row groups [v0-15|g0-15|v16-31|..]
+ * dst_hi (and dst_lo when non-NULL: the bf16 residual src - hi) are bf16, caller-allocated. */
+enum crg_pack_kind { CRG_PACK_LINEAR = 0, CRG_PACK_CONV = 1, CRG_PACK_GEGLU = 2 };
+int crg_pack_weight(crg_ctx* ctx, void* stream, const void* src, int src_dtype, int kind, int n_out, int n_in,
+                    int ksize, void* dst_hi, void* dst_lo);
+/* bias for GEGLU packed the same way (fp32 in, fp32 out) */
+int crg_pack_geglu_bias(crg_ctx* ctx, void* stream, const float* src, int n_out2, float* dst);
+
+/* ---- attention: O = softmax(Q K^T * scale) V ---------------------------------------------------
+ * Replaces the attention core of CrossAttentionOriginal.forward (attention.py:644-658), the sliced
+ * CUDA variant (:415-424) and xformers (:811): heads split 'b n (h d) -> (b h) n d', softmax over
+ * keys, merge.  Flash-style (never materialises Nq x Nk).  bf16 in/out, fp32 softmax/accumulate.
+ *   q: [B][Nq][ldq] (head h at column h*Dh), k: [B][Nk][ldk], vt: [B][H*Dh][ldvt] (V transposed:
+ *   row = channel, column = key), o: [B][Nq][ldo].  Dh % 8 == 0, Dh <= 160. */
+int crg_attention(crg_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                  const void* vt, int64_t ldvt, void* o, int64_t ldo, int B, int H, int Nq, int Nk, int Dh,
+                  float scale, int dtype);
+
+/* ---- row softmax (VAE AttnBlock, model.py:197-199: softmax(w * c^-0.5, dim=2)) ----------------
+ * x,y: [rows][cols] of `dtype` (in place allowed), y = softmax(x * scale) per row. */
+int crg_softmax_rows(crg_ctx* ctx, void* stream, const void* x, void* y, int64_t rows, int cols, int64_t ld,
+                     float scale, int dtype);
+
+/* ---- small-channel direct conv ----------------------------------------------------------------
+ * conv_in (4->320, openaimodel.py:551; VAE 4->512 model.py:494; encoder 3->128 :390), conv_out
+ * (320->4, :755; VAE 128->3 :536; encoder 512->8 :435) and the 1x1 quant_conv / post_quant_conv
+ * (autoencoder.py:302-303): Cin <= 8 or Cout <= 8, ksize 3 (pad 1) or 1, stride 1.
+ * x: [N][H][W][Cin] x_dtype, w: fp32 [Cout][Cin][k][k] (checkpoint layout), bias fp32, y y_dtype. */
+int crg_conv_small(crg_ctx* ctx, void* stream, const void* x, const float* w, const float* bias, void* y,
+                   int N, int H, int W, int Cin, int Cout, int ksize, int x_dtype, int y_dtype);
+
+/* ---- elementwise / layout ------------------------------------------------------------------------ */
+/* timestep_embedding (util.py:151-171): out[b] = [cos(t_b f_i) | sin(t_b f_i)], f_i = exp(-ln(1e4) i/half) */
+int crg_timestep_embedding(crg_ctx* ctx, void* stream, const float* t, void* out, int B, int dim, int dtype);
+/* y = silu(x) (nn.SiLU in emb_layers / time_embed, openaimodel.py:222-228,538-543) */
+int crg_silu(crg_ctx* ctx, void* stream, const void* x, void* y, int64_t n, int dtype);
+/* NCHW (src_dtype) -> NHWC (dst_dtype) and back; used once at the UNet/VAE boundary */
+int crg_nchw_to_nhwc(crg_ctx* ctx, void* stream, const void* src, void* dst, int N, int C, int HW, int src_dtype,
+                     int dst_dtype);
+int crg_nhwc_to_nchw(crg_ctx* ctx, void* stream, const void* src, void* dst, int N, int C, int HW, int src_dtype,
+                     int dst_dtype);
+/* y = a*x + b elementwise with dtype conversion (latent scaling z/0.18215, clamp((x+1)/2,0,1)) */
+int crg_affine_cast(crg_ctx* ctx, void* stream, const void* x, void* y, int64_t n, float a, float b, float lo,
+                    float hi, int src_dtype, int dst_dtype);
+
+/* y = a*x + b*y elementwise (IP-Adapter FaceID: out + ipa_scale * out_ipa, attention.py:681;
+ * ControlNet residual adds, cldm.py:57-65) */
+int crg_axpby(crg_ctx* ctx, void* stream, const void* x, void* y, int64_t n, float a, float b, int dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRG_HIP_H */

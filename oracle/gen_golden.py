@@ -1,0 +1,485 @@
+"""ORACLE tooling - generate the golden vectors under tests/golden/ by importing and
+running the REFERENCE's own modules (read-only mount /root/reference) on CPU in fp32.
+
+TEST INFRASTRUCTURE ONLY; runs in the build container only (the GPU box has no
+/root/reference and only consumes the committed fixtures).  No reference source is
+copied: this script only *imports* it, feeds name-keyed synthetic parameters
+(cremage_amd.synth) and records inputs/outputs.
+
+Recipe (verified there):
+  * sys.path gets /root/reference/modules; bytecode writing is disabled (RO mount);
+  * third-party packages that are absent offline and only needed at import time
+    (omegaconf.ListConfig, pytorch_lightning.LightningModule, torchvision, torchdiffeq,
+    torchsde) are registered as empty `sys.modules` entries - none of them does any
+    arithmetic on this path;
+  * GPU_DEVICE=cpu selects `CrossAttentionOriginal` (attention.py:877-883);
+  * `torch.cuda.is_available` is forced True ONLY around forwards, to skip the
+    Apple-MPS fp16 casts (openaimodel.py:85-90,794-795,814-815; autoencoder.py:334-335)
+    so that the path really runs in fp32.
+
+Usage:  python oracle/gen_golden.py [--only NAME ...] [--full]
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+import types
+
+os.environ["GPU_DEVICE"] = "cpu"
+os.environ.setdefault("LOGLEVEL", "WARNING")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF = "/root/reference/modules"
+GOLD = os.path.join(REPO, "tests", "golden")
+
+from cremage_amd.synth import synth_fill_, synth_input  # noqa: E402
+
+
+def _install_import_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class ListConfig(list):
+        pass
+
+    oc = mod("omegaconf", ListConfig=ListConfig, OmegaConf=object)
+    oc.listconfig = mod("omegaconf.listconfig", ListConfig=ListConfig)
+
+    class LightningModule(torch.nn.Module):
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+    pl = mod("pytorch_lightning", LightningModule=LightningModule)
+    pl.utilities = mod("pytorch_lightning.utilities")
+    pl.utilities.distributed = mod("pytorch_lightning.utilities.distributed", rank_zero_only=lambda f: f)
+    tv = mod("torchvision")
+    tv.utils = mod("torchvision.utils", make_grid=None)
+    tv.transforms = mod("torchvision.transforms")
+    tv.transforms.functional = mod("torchvision.transforms.functional")
+    mod("torchdiffeq", odeint=None)
+    mod("torchsde")
+
+
+_install_import_stubs()
+sys.path.insert(0, REF)
+
+from ldm.modules.diffusionmodules import openaimodel as R_unet  # noqa: E402
+from ldm.modules.diffusionmodules import model as R_vae  # noqa: E402
+from ldm.modules.diffusionmodules import util as R_util  # noqa: E402
+from ldm.modules import attention as R_attn  # noqa: E402
+from ldm.modules.distributions.distributions import DiagonalGaussianDistribution  # noqa: E402
+from ldm.models.autoencoder import AutoencoderKL  # noqa: E402
+from ldm.models.diffusion.ddpm import LatentDiffusion  # noqa: E402
+from ldm.models.diffusion.ddim import DDIMSampler  # noqa: E402
+from ldm.models.diffusion import k_diffusion_samplers as R_ks  # noqa: E402
+from k_diffusion import external as R_kext  # noqa: E402
+from k_diffusion import sampling as R_ksamp  # noqa: E402
+
+assert R_attn.BasicTransformerBlock.ATTENTION_MODES["softmax-original"] is R_attn.CrossAttentionOriginal
+
+
+@contextlib.contextmanager
+def fp32_forward():
+    """Scoped `torch.cuda.is_available() -> True` so the reference skips its fp16 casts."""
+    orig = torch.cuda.is_available
+    torch.cuda.is_available = lambda: True
+    try:
+        with torch.no_grad():
+            yield
+    finally:
+        torch.cuda.is_available = orig
+
+
+def save(name, meta, **arrays):
+    os.makedirs(GOLD, exist_ok=True)
+    out = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()}
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), meta=json.dumps(meta), **out)
+    sz = os.path.getsize(os.path.join(GOLD, name + ".npz"))
+    print(f"[golden] {name}: {sz/1024:.1f} KiB  {list(out)}")
+
+
+SEED = 1234
+
+# ---------------------------------------------------------------------------- leaf ops
+
+
+def g_groupnorm():
+    for tag, cls_eps, C, hw in [("gn32_e5", 1e-5, 64, 8), ("gn32_e5_c320", 1e-5, 320, 4), ("gn_e6", 1e-6, 128, 6)]:
+        if cls_eps == 1e-5:
+            m = R_util.normalization(C)
+        else:
+            m = R_attn.Normalize(C)
+        synth_fill_(m, SEED, prefix=tag + ".")
+        x = synth_input(tag, (2, C, hw, hw), SEED, 1.5) + 0.3
+        with fp32_forward():
+            y = m(x)
+            ys = torch.nn.SiLU()(y)
+        save("op_" + tag, dict(C=C, hw=hw, eps=cls_eps, seed=SEED, prefix=tag + "."), y=y, y_silu=ys)
+
+
+def g_timestep_embedding():
+    t = torch.tensor([0.0, 1.0, 17.25, 499.5, 998.9999, 999.0])
+    with fp32_forward():
+        e320 = R_util.timestep_embedding(t, 320)
+        e64 = R_util.timestep_embedding(t, 64)
+    save("op_timestep_embedding", dict(), t=t, e320=e320, e64=e64)
+
+
+def g_resblock():
+    for tag, cin, cout in [("res_same", 64, 64), ("res_skip", 64, 128), ("res_320", 320, 320)]:
+        hw = 8 if cin < 320 else 4
+        m = R_unet.ResBlock(cin, 256, 0, out_channels=cout)
+        synth_fill_(m, SEED, prefix=tag + ".")
+        x = synth_input(tag + ".x", (2, cin, hw, hw), SEED)
+        emb = synth_input(tag + ".emb", (2, 256), SEED)
+        with fp32_forward():
+            y = m(x, emb)
+        save("blk_" + tag, dict(cin=cin, cout=cout, hw=hw, emb=256, seed=SEED, prefix=tag + "."), y=y)
+
+
+def g_updown():
+    m = R_unet.Downsample(64, True, out_channels=64)
+    synth_fill_(m, SEED, prefix="down.")
+    x = synth_input("down.x", (2, 64, 10, 10), SEED)
+    with fp32_forward():
+        y = m(x)
+    save("blk_downsample", dict(C=64, hw=10, seed=SEED, prefix="down."), y=y)
+    m = R_unet.Upsample(64, True, out_channels=64)
+    synth_fill_(m, SEED, prefix="up.")
+    x = synth_input("up.x", (2, 64, 5, 5), SEED)
+    with fp32_forward():
+        y = m(x)
+    save("blk_upsample", dict(C=64, hw=5, seed=SEED, prefix="up."), y=y)
+
+
+def g_attention():
+    cases = [
+        ("ca_d40_m77", 320, 768, 8, 40, 64, 77),
+        ("ca_d80_m154", 640, 768, 8, 80, 36, 154),
+        ("ca_d160_self", 1280, None, 8, 160, 64, None),
+        ("ca_d64_m77", 128, 96, 2, 64, 100, 77),
+        ("ca_d40_self", 320, None, 8, 40, 200, None),
+    ]
+    for tag, qd, cd, heads, dh, n, mctx in cases:
+        m = R_attn.CrossAttentionOriginal(qd, cd, heads=heads, dim_head=dh)
+        synth_fill_(m, SEED, prefix=tag + ".")
+        x = synth_input(tag + ".x", (2, n, qd), SEED)
+        ctx = synth_input(tag + ".ctx", (2, mctx, cd), SEED) if mctx else None
+        with fp32_forward():
+            y = m(x, context=ctx)
+        save("op_" + tag, dict(query_dim=qd, context_dim=cd, heads=heads, dim_head=dh, n=n, m=mctx, seed=SEED,
+                               prefix=tag + "."), y=y)
+    # LoRA rank-4 branch + IP-Adapter FaceID branch (attention.py:616-641,660-683)
+    tag = "ca_lora_ipa"
+    m = R_attn.CrossAttentionOriginal(128, 96, heads=4, dim_head=32, lora_ranks=[4], lora_weights=[0.7],
+                                      ipa_scale=0.6, ipa_num_tokens=4)
+    synth_fill_(m, SEED, prefix=tag + ".")
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if "_lora_" in name and p.ndim > 0:
+                p.copy_(synth_input(tag + "." + name, p.shape, SEED, 0.2))
+    x = synth_input(tag + ".x", (2, 50, 128), SEED)
+    ctx = synth_input(tag + ".ctx", (2, 81, 96), SEED)
+    with fp32_forward():
+        y = m(x, context=ctx)
+    save("op_" + tag, dict(query_dim=128, context_dim=96, heads=4, dim_head=32, n=50, m=81, lora_ranks=[4],
+                           lora_weights=[0.7], ipa_scale=0.6, ipa_num_tokens=4, seed=SEED, prefix=tag + "."), y=y)
+
+
+def g_transformer():
+    tag = "ff"
+    m = R_attn.FeedForward(64, glu=True)
+    synth_fill_(m, SEED, prefix=tag + ".")
+    x = synth_input(tag + ".x", (2, 30, 64), SEED)
+    with fp32_forward():
+        y = m(x)
+    save("op_ff_geglu", dict(dim=64, n=30, seed=SEED, prefix=tag + "."), y=y)
+
+    tag = "btb"
+    m = R_attn.BasicTransformerBlock(128, 4, 32, context_dim=96, checkpoint=False)
+    synth_fill_(m, SEED, prefix=tag + ".")
+    x = synth_input(tag + ".x", (2, 36, 128), SEED)
+    ctx = synth_input(tag + ".ctx", (2, 77, 96), SEED)
+    with fp32_forward():
+        y = m(x, context=ctx)
+    save("blk_basic_transformer", dict(dim=128, heads=4, dim_head=32, context_dim=96, n=36, m=77, seed=SEED,
+                                       prefix=tag + "."), y=y)
+
+    tag = "st"
+    m = R_attn.SpatialTransformer(128, 4, 32, depth=1, context_dim=96, use_checkpoint=False)
+    synth_fill_(m, SEED, prefix=tag + ".")
+    x = synth_input(tag + ".x", (2, 128, 6, 6), SEED)
+    ctx = synth_input(tag + ".ctx", (2, 77, 96), SEED)
+    with fp32_forward():
+        y = m(x, context=ctx)
+    save("blk_spatial_transformer", dict(C=128, heads=4, dim_head=32, context_dim=96, hw=6, m=77, seed=SEED,
+                                         prefix=tag + "."), y=y)
+
+
+# ---------------------------------------------------------------------------- UNet
+
+TINY_UNET = dict(image_size=32, in_channels=4, out_channels=4, model_channels=64, attention_resolutions=[2, 1],
+                 num_res_blocks=1, channel_mult=[1, 2], num_heads=4, use_spatial_transformer=True,
+                 transformer_depth=1, context_dim=96, use_checkpoint=False, legacy=False)
+SMALL_SD_UNET = dict(image_size=32, in_channels=4, out_channels=4, model_channels=64, attention_resolutions=[4, 2, 1],
+                     num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+                     transformer_depth=1, context_dim=768, use_checkpoint=False, legacy=False)
+SD15_UNET = dict(image_size=32, in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1],
+                 num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+                 transformer_depth=1, context_dim=768, use_checkpoint=False, legacy=False)
+
+
+def _unet_case(name, cfg, B, L, mctx, tvals):
+    m = R_unet.UNetModel(**cfg)
+    synth_fill_(m, SEED, prefix="unet.")
+    x = synth_input(name + ".x", (B, 4, L, L), SEED)
+    ctx = synth_input(name + ".ctx", (B, mctx, cfg["context_dim"]), SEED)
+    t = torch.tensor(tvals, dtype=torch.float32)
+    t0 = time.time()
+    with fp32_forward():
+        y = m(x, timesteps=t, context=ctx)
+    dt = time.time() - t0
+    keys = sorted(k for k, _ in m.named_parameters())
+    save(name, dict(cfg=cfg, B=B, L=L, m=mctx, seed=SEED, prefix="unet.", n_params=sum(p.numel() for p in m.parameters()),
+                    n_keys=len(keys), key_sample=keys[:: max(1, len(keys) // 40)], ref_cpu_seconds=dt,
+                    threads=torch.get_num_threads()), t=t, y=y)
+    return m
+
+
+def g_unet_tiny():
+    _unet_case("unet_tiny", TINY_UNET, 2, 16, 77, [10.0, 731.25])
+
+
+def g_unet_small_sd():
+    _unet_case("unet_small_sd", SMALL_SD_UNET, 2, 16, 77, [3.5, 900.0])
+
+
+def g_unet_sd15_full():
+    # Full-size SD1.5 UNet (859.52 M params), B=2 (one image x CFG), L=64 - config 1's unit of work.
+    _unet_case("unet_sd15_full", SD15_UNET, 2, 64, 77, [981.5, 981.5])
+
+
+# ---------------------------------------------------------------------------- VAE
+
+TINY_DD = dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2],
+               num_res_blocks=1, attn_resolutions=[], dropout=0.0)
+SD15_DD = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+               num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+
+
+def g_vae_blocks():
+    tag = "vres"
+    m = R_vae.ResnetBlock(in_channels=64, out_channels=128, dropout=0.0, temb_channels=0)
+    synth_fill_(m, SEED, prefix=tag + ".")
+    x = synth_input(tag + ".x", (2, 64, 8, 8), SEED)
+    with fp32_forward():
+        y = m(x, None)
+    save("blk_vae_resnet", dict(cin=64, cout=128, hw=8, seed=SEED, prefix=tag + "."), y=y)
+
+    tag = "vattn"
+    m = R_vae.AttnBlock(64)
+    synth_fill_(m, SEED, prefix=tag + ".")
+    x = synth_input(tag + ".x", (2, 64, 6, 6), SEED)
+    with fp32_forward():
+        y = m(x)
+    save("blk_vae_attn", dict(C=64, hw=6, seed=SEED, prefix=tag + "."), y=y)
+
+    tag = "vdown"
+    m = R_vae.Downsample(64, True)
+    synth_fill_(m, SEED, prefix=tag + ".")
+    x = synth_input(tag + ".x", (2, 64, 10, 10), SEED)
+    with fp32_forward():
+        y = m(x)
+    save("blk_vae_downsample", dict(C=64, hw=10, seed=SEED, prefix=tag + "."), y=y)
+
+    tag = "vup"
+    m = R_vae.Upsample(64, True)
+    synth_fill_(m, SEED, prefix=tag + ".")
+    x = synth_input(tag + ".x", (2, 64, 5, 5), SEED)
+    with fp32_forward():
+        y = m(x)
+    save("blk_vae_upsample", dict(C=64, hw=5, seed=SEED, prefix=tag + "."), y=y)
+
+
+def _make_ae(dd):
+    ae = AutoencoderKL(ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4)
+    synth_fill_(ae, SEED, prefix="vae.")
+    return ae.eval()
+
+
+def g_vae_tiny():
+    ae = _make_ae(TINY_DD)
+    z = synth_input("vae_tiny.z", (2, 4, 8, 8), SEED)
+    img = synth_input("vae_tiny.img", (2, 3, 16, 16), SEED, 0.5).clamp(-1, 1)
+    noise = synth_input("vae_tiny.noise", (2, 4, 8, 8), SEED)
+    with fp32_forward():
+        dec = ae.decode(z)
+        # AutoencoderKL.encode (autoencoder.py:324-331) minus its unconditional x.half() at :327
+        moments = ae.quant_conv(ae.encoder(img))
+        post = DiagonalGaussianDistribution(moments)
+        sample = post.mean + post.std * noise
+    save("vae_tiny", dict(dd=TINY_DD, seed=SEED, prefix="vae."), dec=dec, moments=moments, sample=sample)
+
+
+def g_vae_sd15_full():
+    ae = _make_ae(SD15_DD)
+    z = synth_input("vae_full.z", (1, 4, 64, 64), SEED)
+    t0 = time.time()
+    with fp32_forward():
+        dec = ae.decode(z / 0.18215)
+    dt = time.time() - t0
+    img = torch.clamp((dec + 1.0) / 2.0, 0.0, 1.0)  # image_generator.py:1013
+    save("vae_sd15_full_decode", dict(dd=SD15_DD, seed=SEED, prefix="vae.", ref_cpu_seconds=dt,
+                                      threads=torch.get_num_threads(), scale_factor=0.18215),
+         dec_f16=dec.half(), dec_sub=dec[:, :, ::8, ::8].contiguous(), pix_stats=torch.tensor(
+             [img.mean().item(), img.std().item(), dec.abs().max().item()]))
+    x = synth_input("vae_full.img", (1, 3, 256, 256), SEED, 0.5).clamp(-1, 1)
+    with fp32_forward():
+        moments = ae.quant_conv(ae.encoder(x))
+    save("vae_sd15_full_encode", dict(dd=SD15_DD, seed=SEED, prefix="vae.", hw=256), moments=moments)
+
+
+# ---------------------------------------------------------------------------- schedules & trajectories
+
+
+def _tiny_ldm():
+    ldm = LatentDiffusion(first_stage_config={"target": "ldm.models.autoencoder.AutoencoderKL",
+                                              "params": dict(ddconfig=TINY_DD, lossconfig={"target": "torch.nn.Identity"},
+                                                             embed_dim=4)},
+                          cond_stage_config={"target": "torch.nn.Identity"},
+                          unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": TINY_UNET},
+                          linear_start=0.00085, linear_end=0.012, timesteps=1000, conditioning_key="crossattn",
+                          scale_factor=0.18215, use_ema=False, cond_stage_trainable=False, first_stage_key="jpg",
+                          cond_stage_key="txt", image_size=16, channels=4)
+    synth_fill_(ldm.model.diffusion_model, SEED, prefix="unet.")
+    synth_fill_(ldm.first_stage_model, SEED, prefix="vae.")
+    return ldm.eval()
+
+
+def g_schedules():
+    ldm = _tiny_ldm()
+    acp = ldm.alphas_cumprod
+    den = R_kext.CompVisDenoiser(ldm, False)
+    sig20 = den.get_sigmas(20)
+    sig5 = den.get_sigmas(5)
+    probe = torch.tensor([0.03, 0.5, 1.0, 3.3, 14.6146, 20.0])
+    s2t = den.sigma_to_t(probe)
+    dd = DDIMSampler(ldm)
+    with contextlib.redirect_stdout(open(os.devnull, "w")):
+        orig = torch.cuda.is_available
+        torch.cuda.is_available = lambda: True  # fp32 tables (ddim.py:43-46); model is on cpu so .to(device) is a no-op
+        torch.Tensor.cuda_orig = None
+        try:
+            dd.register_buffer = lambda name, attr: setattr(dd, name, attr)
+            dd.make_schedule(ddim_num_steps=20, ddim_eta=0.0, verbose=False)
+        finally:
+            torch.cuda.is_available = orig
+    save("schedules", dict(linear_start=0.00085, linear_end=0.012, timesteps=1000),
+         alphas_cumprod=acp, sigmas_table=den.sigmas, get_sigmas_20=sig20, get_sigmas_5=sig5, sigma_probe=probe,
+         sigma_to_t=s2t, ddim_timesteps_20=np.asarray(dd.ddim_timesteps), ddim_alphas_20=np.asarray(dd.ddim_alphas),
+         ddim_alphas_prev_20=np.asarray(dd.ddim_alphas_prev))
+
+
+def g_trajectories():
+    """5-step Euler / Euler-a through the reference's own sampler stack
+    (EulerSampler -> sample_euler -> LDMWrapperForKDiffusion -> CompVisDenoiser ->
+    LatentDiffusion.apply_model -> DiffusionWrapper -> UNetModel), tiny UNet, CFG 7.5,
+    then decode_first_stage; plus a DDIM img2img (S=20, t_enc=3)."""
+    ldm = _tiny_ldm()
+    B, L = 2, 16
+    c = synth_input("traj.c", (B, 77, 96), SEED)
+    uc = synth_input("traj.uc", (B, 77, 96), SEED)
+    x0 = synth_input("traj.x0", (B, 4, L, L), SEED)
+    noises = [synth_input(f"traj.noise{i}", (B, 4, L, L), SEED) for i in range(5)]
+
+    R_ks.trange = R_ksamp.trange = lambda *a, **k: range(*a)  # silence tqdm
+
+    for cls, nm in [(R_ks.EulerSampler, "euler"), (R_ks.EulerAncestralSampler, "euler_a")]:
+        s = cls(ldm)
+        it = iter(noises)
+        orig_randn_like = torch.randn_like
+        if nm == "euler_a":
+            torch.randn_like = lambda x, **k: next(it)  # captured noise instead of the global RNG (sampling.py:61-62)
+        try:
+            with fp32_forward(), contextlib.redirect_stdout(open(os.devnull, "w")):
+                # sample() opens torch.autocast(device_type=GPU_DEVICE) when cuda "is available"
+                # (k_diffusion_samplers.py:244-249); on CPU autocast would drop to bf16, so call the
+                # two halves of sample() directly: _sample_common_prep then do_sample (:196-253).
+                s._sample_common_prep(S=5, batch_size=B, shape=[4, L, L], conditioning=c,
+                                      unconditional_guidance_scale=7.5, unconditional_conditioning=uc, x0=x0)
+                x, _ = s.do_sample()
+                img = ldm.decode_first_stage(x)
+        finally:
+            torch.randn_like = orig_randn_like
+        save("traj_" + nm, dict(B=B, L=L, S=5, cfg=7.5, seed=SEED, unet=TINY_UNET, dd=TINY_DD), sigmas=s.sigmas, x=x, img=img)
+
+    dd = DDIMSampler(ldm)
+    dd.register_buffer = lambda name, attr: setattr(dd, name, attr)
+    orig = torch.cuda.is_available
+    torch.cuda.is_available = lambda: True
+    try:
+        dd.make_schedule(ddim_num_steps=20, ddim_eta=0.0, verbose=False)
+    finally:
+        torch.cuda.is_available = orig
+    import ldm.models.diffusion.ddim as R_ddim
+    R_ddim.tqdm = lambda it, **k: it
+    img_in = synth_input("traj.img", (B, 3, 32, 32), SEED, 0.5).clamp(-1, 1)
+    enc_noise = synth_input("traj.encnoise", (B, 4, L, L), SEED)
+    fwd_noise = synth_input("traj.fwdnoise", (B, 4, L, L), SEED)
+    with fp32_forward(), contextlib.redirect_stdout(open(os.devnull, "w")):
+        moments = ldm.first_stage_model.quant_conv(ldm.first_stage_model.encoder(img_in))
+        post = DiagonalGaussianDistribution(moments)
+        init_latent = 0.18215 * (post.mean + post.std * enc_noise)  # ddpm.py:575-582
+        z_enc = dd.stochastic_encode(init_latent, torch.tensor([3] * B), noise=fwd_noise)
+        x = dd.decode(z_enc, c, 3, unconditional_guidance_scale=7.5, unconditional_conditioning=uc)
+        img = ldm.decode_first_stage(x)
+    save("traj_ddim_img2img", dict(B=B, L=L, S=20, t_enc=3, cfg=7.5, seed=SEED, unet=TINY_UNET, dd=TINY_DD),
+         init_latent=init_latent, z_enc=z_enc, x=x, img=img)
+
+
+def g_alphas_doc():
+    """The reference's only numeric known-answer artefact for this path: 1000 float64 alphas_cumprod values
+    printed in docs/developers/ddpm_cumprod_alpha_example_values.md (data only, no source)."""
+    import re
+    vals = {}
+    for line in open("/root/reference/docs/developers/ddpm_cumprod_alpha_example_values.md"):
+        m = re.match(r"^\[(\d+)\]\s+([0-9.eE+-]+)\s*$", line)
+        if m:
+            vals[int(m.group(1))] = float(m.group(2))
+    assert sorted(vals) == list(range(1000))
+    save("alphas_cumprod_doc", dict(linear_start=0.00085, linear_end=0.012, timesteps=1000,
+                                    source="docs/developers/ddpm_cumprod_alpha_example_values.md"),
+         alphas_cumprod=np.asarray([vals[i] for i in range(1000)], dtype=np.float64))
+
+
+CASES = dict(alphas_doc=g_alphas_doc, groupnorm=g_groupnorm, timestep_embedding=g_timestep_embedding, resblock=g_resblock, updown=g_updown,
+             attention=g_attention, transformer=g_transformer, unet_tiny=g_unet_tiny, unet_small_sd=g_unet_small_sd,
+             vae_blocks=g_vae_blocks, vae_tiny=g_vae_tiny, schedules=g_schedules, trajectories=g_trajectories)
+FULL = dict(unet_sd15_full=g_unet_sd15_full, vae_sd15_full=g_vae_sd15_full)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*")
+    ap.add_argument("--full", action="store_true", help="also run the full-size SD1.5 UNet / VAE cases (minutes)")
+    a = ap.parse_args()
+    todo = dict(CASES)
+    if a.full:
+        todo.update(FULL)
+    if a.only:
+        allc = dict(CASES, **FULL)
+        todo = {k: allc[k] for k in a.only}
+    for k, fn in todo.items():
+        t0 = time.time()
+        fn()
+        print(f"[golden] case {k} done in {time.time()-t0:.1f}s")
