@@ -12,13 +12,13 @@ constexpr int GN_MAX_GROUPS = 32;
 // fp32 accumulation error scales with the spread around K_g and not with |mean|^2 / var.
 // grid (chunks, N); thread = (row lane, 8-channel column).
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, int C, int HW,
+__global__ __launch_bounds__(512) void gn_stats_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, int C, int HW,
                                                        int groups, int rows_per_chunk, float* __restrict__ part,
                                                        float* __restrict__ kbuf) {
   __shared__ float s1[GN_MAX_GROUPS], s2[GN_MAX_GROUPS], shiftv[GN_MAX_GROUPS];
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int tpr = C >> 3;                 // threads per row
-  const int rpi = 256 / tpr;              // rows per iteration
+  const int rpi = blockDim.x / tpr;       // rows per iteration
   const int t = threadIdx.x;
   const int col = t % tpr, rl = t / tpr;
   const int gs = C / groups;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 
 // ---- GroupNorm pass 2: finalise statistics (fp64 combine) and apply affine (+SiLU) ---------------
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, int C, int HW,
+__global__ __launch_bounds__(512) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, int C, int HW,
                                                        int groups, int rows_per_block, int n_chunks,
                                                        const float* __restrict__ part, const float* __restrict__ kbuf,
                                                        const float* __restrict__ gamma,
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   }
   __syncthreads();
   const int tpr = C >> 3;
-  const int rpi = 256 / tpr;
+  const int rpi = blockDim.x / tpr;
   const int col = t % tpr, rl = t / tpr;
   if (rl >= rpi) return;
   const int c0 = col * 8;
@@ -222,7 +222,8 @@ extern "C" int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const vo
   if (!ctx) return -22;
   CRG_REQUIRE(ctx, N > 0 && HW > 0 && C > 0, "groupnorm: empty input");
   CRG_REQUIRE(ctx, groups > 0 && groups <= GN_MAX_GROUPS && C % groups == 0, "groupnorm: groups=%d C=%d unsupported", groups, C);
-  CRG_REQUIRE(ctx, C % 8 == 0 && C <= 2048 * 8 && (C >> 3) <= 256, "groupnorm: C=%d must be a multiple of 8 and <= 2048", C);
+  CRG_REQUIRE(ctx, C % 8 == 0 && (C >> 3) <= 512, "groupnorm: C=%d must be a multiple of 8 and <= 4096", C);
+  const int threads = (C >> 3) <= 256 ? 256 : 512;
   if (!x2) C1 = C;
   CRG_REQUIRE(ctx, C1 > 0 && C1 <= C && C1 % 8 == 0 && (C - C1) % 8 == 0, "groupnorm: concat split C1=%d of C=%d unsupported", C1, C);
   CRG_REQUIRE(ctx, dtype == CRG_BF16 || dtype == CRG_F32, "groupnorm: dtype %d unsupported", dtype);
@@ -242,12 +243,12 @@ extern "C" int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const vo
   crg_prof_scope ps(ctx, st, CRG_K_GROUPNORM, 8.0 * elems, elems * es * 3);
   dim3 grid(chunks, N);
   if (dtype == CRG_BF16) {
-    hipLaunchKernelGGL(gn_stats_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (const bf16*)x2, C1, C, HW, groups, rpc, part, kbuf);
-    hipLaunchKernelGGL(gn_apply_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (const bf16*)x2, C1, C, HW, groups, rpc, chunks,
+    hipLaunchKernelGGL(gn_stats_kernel<bf16>, grid, dim3(threads), 0, st, (const bf16*)x, (const bf16*)x2, C1, C, HW, groups, rpc, part, kbuf);
+    hipLaunchKernelGGL(gn_apply_kernel<bf16>, grid, dim3(threads), 0, st, (const bf16*)x, (const bf16*)x2, C1, C, HW, groups, rpc, chunks,
                        part, kbuf, gamma, beta, eps, fuse_silu, (bf16*)y);
   } else {
-    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)x2, C1, C, HW, groups, rpc, part, kbuf);
-    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)x2, C1, C, HW, groups, rpc, chunks,
+    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(threads), 0, st, (const float*)x, (const float*)x2, C1, C, HW, groups, rpc, part, kbuf);
+    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(threads), 0, st, (const float*)x, (const float*)x2, C1, C, HW, groups, rpc, chunks,
                        part, kbuf, gamma, beta, eps, fuse_silu, (float*)y);
   }
   CRG_CHECK_LAUNCH(ctx, "groupnorm");

@@ -43,24 +43,24 @@ def zero_init_module(module):
 
 
 # ---------------------------------------------------------------------------------------------- LoRA folding
-_merge_cache = {}
+_merge_cache = ops.TensorKeyedCache()
 
 
 def _tkey(t: torch.Tensor):
-    return (t.data_ptr(), t._version, t.dtype, t.device, tuple(t.shape))
+    return (id(t), t.data_ptr(), t._version, t.dtype, t.device, tuple(t.shape))
 
 
 def effective_weight(base: torch.Tensor, downs, ups, alphas, ranks, weights) -> torch.Tensor:
-    """W + sum_i weights[i] * (alpha_i / rank_i) * Up_i @ Down_i  (fp32, cached on all operands).
-    Equals the reference's additive branch `d = up(down(x)); out += d * w * (alpha / rank)`."""
+    """W + sum_i weights[i] * (alpha_i / rank_i) * Up_i @ Down_i  (fp32, cached on the identity and
+    version of every operand).  Equals the reference's additive branch
+    `d = up(down(x)); out += d * w * (alpha / rank)` (attention.py:616-619 and its 7 siblings)."""
     if not ranks:
         return base
-    key = (_tkey(base),) + tuple((_tkey(d.weight), _tkey(u.weight), _tkey(a), float(w)) for d, u, a, w in zip(downs, ups, alphas, weights))
-    hit = _merge_cache.get(key)
+    srcs = (base,) + tuple(d.weight for d in downs) + tuple(u.weight for u in ups) + tuple(alphas)
+    extra = tuple(float(w) for w in weights)
+    hit = _merge_cache.get(srcs, extra)
     if hit is not None:
         return hit
-    if len(_merge_cache) > 2048:
-        _merge_cache.clear()
     with torch.no_grad():
         w = base.detach().float().reshape(base.shape[0], -1).clone()
         for d, u, a, lw, r in zip(downs, ups, alphas, weights, ranks):
@@ -68,8 +68,7 @@ def effective_weight(base: torch.Tensor, downs, ups, alphas, ranks, weights) -> 
             up = u.weight.detach().float().reshape(u.weight.shape[0], -1)
             w += (up @ dn) * (float(lw) * float(a.detach().float()) / float(r))
         w = w.reshape(base.shape).contiguous()
-    _merge_cache[key] = w
-    return w
+    return _merge_cache.put(srcs, extra, w)
 
 
 def _lora_lists(obj, prefix: str, in_dim: int, out_dim: int, ranks, conv: bool = False):

@@ -63,18 +63,61 @@ def _p(t: Optional[torch.Tensor]):
 
 
 # ---------------------------------------------------------------------------------- weight cache
-_pack_cache = {}
-_f32_cache = {}
-_PACK_CACHE_MAX = 4096
+class TensorKeyedCache:
+    """Cache of values derived from torch tensors (packed weights, fp32 copies, merged LoRA weights).
+
+    An entry is keyed on the IDENTITY of its source tensors (id + weakref) and stamped with their
+    (data_ptr, _version, dtype, device): it is hit only while the very same tensor objects still hold
+    the very same, unmodified storage.  Keying on data_ptr alone would be wrong - the caching allocator
+    hands the address of a freed parameter to the next model's parameter of the same shape.  Entries
+    die with their sources (weakref callbacks), so `load_state_dict` (in-place copy -> _version bump),
+    LoRA `setattr` of fresh Parameters (image_generator.py:408-453) and `.to()/.half()` (new storage)
+    all invalidate correctly."""
+
+    def __init__(self, max_entries: int = 8192):
+        self._d = {}
+        self._max = max_entries
+
+    @staticmethod
+    def _stamp(t: torch.Tensor):
+        return (t.data_ptr(), t._version, t.dtype, t.device, tuple(t.shape))
+
+    def get(self, tensors, extra=()):
+        key = (tuple(id(t) for t in tensors), extra)
+        e = self._d.get(key)
+        if e is None:
+            return None
+        refs, stamps, value = e
+        for t, r, st in zip(tensors, refs, stamps):
+            if r() is not t or self._stamp(t) != st:
+                self._d.pop(key, None)
+                return None
+        return value
+
+    def put(self, tensors, extra, value):
+        import weakref
+        if len(self._d) >= self._max:
+            self._d.clear()
+        key = (tuple(id(t) for t in tensors), extra)
+        d = self._d
+
+        def _drop(_ref, key=key, d=d):
+            d.pop(key, None)
+
+        self._d[key] = (tuple(weakref.ref(t, _drop) for t in tensors), tuple(self._stamp(t) for t in tensors), value)
+        return value
+
+    def clear(self):
+        self._d.clear()
+
+
+_pack_cache = TensorKeyedCache()
+_f32_cache = TensorKeyedCache()
 
 
 def clear_weight_cache():
     _pack_cache.clear()
     _f32_cache.clear()
-
-
-def _key(w: torch.Tensor, *extra):
-    return (w.data_ptr(), w._version, w.dtype, w.device, tuple(w.shape), *extra)
 
 
 def f32_vec(v: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -83,13 +126,9 @@ def f32_vec(v: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
         return None
     if v.dtype == torch.float32 and v.is_contiguous():
         return v.detach()
-    k = _key(v)
-    r = _f32_cache.get(k)
+    r = _f32_cache.get((v,))
     if r is None:
-        if len(_f32_cache) > _PACK_CACHE_MAX:
-            _f32_cache.clear()
-        r = v.detach().float().contiguous()
-        _f32_cache[k] = r
+        r = _f32_cache.put((v,), (), v.detach().float().contiguous())
     return r
 
 
@@ -98,12 +137,9 @@ def packed_weight(w: torch.Tensor, kind: int, split: bool) -> Tuple[torch.Tensor
     _need_cuda(w)
     if kind == L.PACK_LINEAR and not split and w.dtype == torch.bfloat16 and w.is_contiguous():
         return w.detach().reshape(w.shape[0], -1), None  # zero-copy: already the packed image
-    k = _key(w, kind, split)
-    r = _pack_cache.get(k)
+    r = _pack_cache.get((w,), (kind, split))
     if r is not None:
         return r
-    if len(_pack_cache) > _PACK_CACHE_MAX:
-        _pack_cache.clear()
     src = w.detach().contiguous()
     n_out = src.shape[0]
     if kind == L.PACK_CONV:
@@ -116,19 +152,17 @@ def packed_weight(w: torch.Tensor, kind: int, split: bool) -> Tuple[torch.Tensor
     lo = torch.empty_like(hi) if split else None
     h = _h(w)
     L.check(L.load().crg_pack_weight(h, _st(), _p(src), _dt(src), kind, n_out, n_in, ks, _p(hi), _p(lo)), h, "crg_pack_weight")
-    _pack_cache[k] = (hi, lo)
-    return hi, lo
+    return _pack_cache.put((w,), (kind, split), (hi, lo))
 
 
 def packed_geglu_bias(b: torch.Tensor) -> torch.Tensor:
-    k = _key(b, "geglu_bias")
-    r = _pack_cache.get(k)
+    r = _pack_cache.get((b,), ("geglu_bias",))
     if r is None:
         src = b.detach().float().contiguous()
         r = torch.empty_like(src)
         h = _h(b)
         L.check(L.load().crg_pack_geglu_bias(h, _st(), _p(src), src.numel(), _p(r)), h, "crg_pack_geglu_bias")
-        _pack_cache[k] = r
+        _pack_cache.put((b,), ("geglu_bias",), r)
     return r
 
 

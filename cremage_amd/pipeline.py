@@ -1,0 +1,88 @@
+"""txt2img / img2img drivers over the HIP UNet + VAE: the numeric core of the reference's call sites
+`sd.txt2img.generate` / `sd.img2img.generate` -> `image_generator.generate`
+(modules/sd/image_generator.py:569-1268), without the app shell (prompt parsing, CLIP, PNG metadata, UI
+queues - all out of scope).  Conditioning arrives as tensors ([b, 77*n, 768]), exactly what
+`model.get_learned_conditioning` hands to the sampler at image_generator.py:785-808.
+
+Step structure reproduced (file:line of the reference):
+  txt2img : sampler.sample(S, conditioning=c, batch_size, shape=[4,H/8,W/8], cfg, uc)      :958-967
+            decode_first_stage per image, clamp((x+1)/2, 0, 1)                             :1007-1015
+  img2img : encode_first_stage -> get_first_stage_encoding (posterior sample * 0.18215)    :721
+            t_enc = int(strength * steps); DDIM stochastic_encode + decode                 :727, :147-248
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+
+from . import ops
+from .ldm_hip.latent_diffusion import LatentDiffusion
+from .ldm_hip.unet import UNetModel
+from .ldm_hip.vae import AutoencoderKL
+from .samplers import DDIMSampler, EulerAncestralSampler, EulerSampler
+from .synth import synth_fill_
+
+SD15_UNET = dict(image_size=32, in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1],
+                 num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True, transformer_depth=1,
+                 context_dim=768, use_checkpoint=True, legacy=False)  # v1-inference.yaml:29-44
+SD15_VAE_DD = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+                   num_res_blocks=2, attn_resolutions=[], dropout=0.0)  # v1-inference.yaml:51-65
+
+SAMPLERS = {"euler": EulerSampler, "euler_a": EulerAncestralSampler}  # sampler_utils.py:36-66 names "Euler", "Euler a"
+
+
+def build_synthetic_ldm(unet_cfg=None, vae_dd=None, device="cuda", unet_dtype=torch.bfloat16, vae_dtype=torch.float32,
+                        seed: int = 1234) -> LatentDiffusion:
+    """LatentDiffusion with name-keyed synthetic weights (no checkpoint exists offline).
+    Parameters are created on CPU in fp32, filled, then cast/moved - the same order as the reference's
+    load_model_from_config (load_state_dict -> .half() -> .to(device), image_generator.py:345,489-493)."""
+    unet = UNetModel(**(unet_cfg or SD15_UNET))
+    vae = AutoencoderKL(vae_dd or SD15_VAE_DD, None, 4)
+    synth_fill_(unet, seed, prefix="unet.")
+    synth_fill_(vae, seed, prefix="vae.")
+    ldm = LatentDiffusion(unet, vae)
+    ldm.model.to(unet_dtype)
+    ldm.first_stage_model.to(vae_dtype)
+    return ldm.to(device).eval()
+
+
+@torch.no_grad()
+def decode_images(ldm: LatentDiffusion, samples: torch.Tensor, batch_decode: bool = True) -> torch.Tensor:
+    """latents [b,4,L,L] -> images [b,3,8L,8L] fp32 in [0,1] (image_generator.py:1007-1015).  The reference
+    decodes one image at a time to fit 8-24 GB cards (`save_memory`, options.py:268-273); with 288 GB the
+    whole batch is decoded in one pass unless `batch_decode=False`."""
+    if batch_decode:
+        x = ldm.decode_first_stage(samples)
+    else:
+        x = torch.cat([ldm.decode_first_stage(s[None]) for s in samples])
+    return ops.affine_cast(x, 0.5, 0.5, torch.float32, 0.0, 1.0)
+
+
+@torch.no_grad()
+def txt2img(ldm: LatentDiffusion, c: torch.Tensor, uc: Optional[torch.Tensor], *, steps: int = 20, sampler: str = "euler_a",
+            cfg_scale: float = 7.5, height: int = 512, width: int = 512, x0: Optional[torch.Tensor] = None,
+            noise_sampler: Optional[Callable] = None, decode: bool = True):
+    """Returns (images or None, final latents)."""
+    b = c.shape[0]
+    shape = [4, height // 8, width // 8]
+    smp = SAMPLERS[sampler](ldm)
+    smp.noise_sampler = noise_sampler
+    samples, _ = smp.sample(S=steps, conditioning=c, batch_size=b, shape=shape, verbose=False,
+                            unconditional_guidance_scale=cfg_scale, unconditional_conditioning=uc, x0=x0)
+    return (decode_images(ldm, samples) if decode else None), samples
+
+
+@torch.no_grad()
+def img2img(ldm: LatentDiffusion, init_image: torch.Tensor, c: torch.Tensor, uc: Optional[torch.Tensor], *, steps: int = 20,
+            strength: float = 0.75, cfg_scale: float = 7.5, enc_noise: Optional[torch.Tensor] = None,
+            fwd_noise: Optional[torch.Tensor] = None, decode: bool = True):
+    """SD1.5 img2img as the reference drives it: sampler forced to DDIM (image_generator.py:679-681)."""
+    b = init_image.shape[0]
+    init_latent = ldm.get_first_stage_encoding(ldm.encode_first_stage(init_image), enc_noise)
+    t_enc = int(strength * steps)
+    smp = DDIMSampler(ldm)
+    smp.make_schedule(ddim_num_steps=steps, ddim_eta=0.0, verbose=False)
+    z_enc = smp.stochastic_encode(init_latent, torch.tensor([t_enc] * b, device=init_latent.device), noise=fwd_noise)
+    samples = smp.decode(z_enc, c, t_enc, unconditional_guidance_scale=cfg_scale, unconditional_conditioning=uc)
+    return (decode_images(ldm, samples) if decode else None), samples

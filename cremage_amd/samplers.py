@@ -1,0 +1,368 @@
+"""Sampler loop, CFG wrapper and schedules - these STAY ON PYTORCH by design (BASELINE.json
+north_star: "The k_diffusion sampler loop ... stay on PyTorch-ROCm so Cremage's generation-info /
+LoRA / ControlNet hooks still attach").  All tensors here are [b, 4, L, L] fp32 latents and scalars;
+the per-step cost is the UNet call behind `eps_model`.
+
+Mirrors (behaviour, names and argument meaning):
+  DiscreteSchedule / DiscreteEpsDDPMDenoiser / CompVisDenoiser   modules/k_diffusion/external.py:41-147
+  LDMWrapperForKDiffusion (CFG batch doubling)                    modules/ldm/models/diffusion/ldm_wrapper_for_k_diffusion.py:20-106
+  sample_euler / sample_euler_ancestral / get_ancestral_step      modules/k_diffusion/sampling.py:51-58,118-163
+  KDiffusionSamplerBase / EulerSampler / EulerAncestralSampler    modules/ldm/models/diffusion/k_diffusion_samplers.py:63-319
+  DDIMSampler.make_schedule / stochastic_encode / decode          modules/ldm/models/diffusion/ddim.py:38-75,615-676
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+
+def append_zero(x):
+    return torch.cat([x, x.new_zeros([1])])
+
+
+def append_dims(x, target_dims):
+    dims_to_append = target_dims - x.ndim
+    if dims_to_append < 0:
+        raise ValueError(f'input has {x.ndim} dims but target_dims is {target_dims}, which is less')
+    return x[(...,) + (None,) * dims_to_append]
+
+
+def make_beta_schedule(schedule="linear", n_timestep=1000, linear_start=0.00085, linear_end=0.012):
+    """ldm/modules/diffusionmodules/util.py:21-43 ('linear' is what SD uses)."""
+    if schedule != "linear":
+        raise ValueError(f"schedule '{schedule}' unknown.")
+    betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2
+    return betas.numpy()
+
+
+def make_alphas_cumprod(n_timestep=1000, linear_start=0.00085, linear_end=0.012) -> torch.Tensor:
+    """DDPM.register_schedule ddpm.py:134-186: np.cumprod(1 - betas) stored as an fp32 buffer."""
+    betas = make_beta_schedule("linear", n_timestep, linear_start, linear_end)
+    return torch.tensor(np.cumprod(1.0 - betas, axis=0), dtype=torch.float32)
+
+
+class DiscreteSchedule(nn.Module):
+    """external.py:41-84."""
+
+    def __init__(self, sigmas, quantize):
+        super().__init__()
+        self.register_buffer('sigmas', sigmas)
+        self.register_buffer('log_sigmas', sigmas.log())
+        self.quantize = quantize
+
+    @property
+    def sigma_min(self):
+        return self.sigmas[0]
+
+    @property
+    def sigma_max(self):
+        return self.sigmas[-1]
+
+    def get_sigmas(self, n=None):
+        if n is None:
+            return append_zero(self.sigmas.flip(0))
+        t_max = len(self.sigmas) - 1
+        t = torch.linspace(t_max, 0, n, device=self.sigmas.device)
+        return append_zero(self.t_to_sigma(t))
+
+    def sigma_to_t(self, sigma, quantize=None):
+        quantize = self.quantize if quantize is None else quantize
+        log_sigma = sigma.log()
+        dists = log_sigma - self.log_sigmas[:, None]
+        if quantize:
+            return dists.abs().argmin(dim=0).view(sigma.shape)
+        low_idx = dists.ge(0).cumsum(dim=0).argmax(dim=0).clamp(max=self.log_sigmas.shape[0] - 2)
+        high_idx = low_idx + 1
+        low, high = self.log_sigmas[low_idx], self.log_sigmas[high_idx]
+        w = (low - log_sigma) / (low - high)
+        w = w.clamp(0, 1)
+        t = (1 - w) * low_idx + w * high_idx
+        return t.view(sigma.shape)
+
+    def t_to_sigma(self, t):
+        t = t.float()
+        low_idx, high_idx, w = t.floor().long(), t.ceil().long(), t.frac()
+        log_sigma = (1 - w) * self.log_sigmas[low_idx] + w * self.log_sigmas[high_idx]
+        return log_sigma.exp()
+
+
+class CompVisDenoiser(DiscreteSchedule):
+    """DiscreteEpsDDPMDenoiser + CompVisDenoiser (external.py:87-147): sigma = sqrt((1-a)/a);
+    forward: eps = model.apply_model(x * c_in, sigma_to_t(sigma), **kw); return x + eps * (-sigma)."""
+
+    def __init__(self, model, quantize=False, device='cpu'):
+        alphas_cumprod = model.alphas_cumprod
+        super().__init__(((1 - alphas_cumprod) / alphas_cumprod) ** 0.5, quantize)
+        self.inner_model = model
+        self.sigma_data = 1.
+
+    def get_scalings(self, sigma):
+        c_out = -sigma
+        c_in = 1 / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
+        return c_out, c_in
+
+    def get_eps(self, *args, **kwargs):
+        return self.inner_model.apply_model(*args, **kwargs)
+
+    def forward(self, input, sigma, **kwargs):
+        c_out, c_in = [append_dims(x, input.ndim) for x in self.get_scalings(sigma)]
+        eps = self.get_eps(input * c_in, self.sigma_to_t(sigma), **kwargs)
+        return input + eps * c_out
+
+
+class LDMWrapperForKDiffusion(nn.Module):
+    """ldm_wrapper_for_k_diffusion.py:20-106: classifier-free guidance by batch doubling, applied to the
+    DENOISED outputs of the CompVis wrapper.  The concatenated conditioning is built once and reused
+    for every step (the reference rebuilds the same `torch.cat` each step, :67-92), which lets the
+    cross-attention K/V cache of cremage_amd.ldm_hip.transformer hit."""
+
+    def __init__(self, compviz_wrapper_model, c, unconditional_conditioning, unconditional_guidance_scale: float):
+        super().__init__()
+        self.compviz_model = compviz_wrapper_model
+        self.alphas_cumprod = compviz_wrapper_model.inner_model.alphas_cumprod
+        self.ddpm_num_timesteps = compviz_wrapper_model.inner_model.num_timesteps
+        self.c = c
+        self.unconditional_conditioning = unconditional_conditioning
+        self.unconditional_guidance_scale = unconditional_guidance_scale
+        self._c_in = None
+
+    def _cat_cond(self):
+        if self._c_in is None:
+            c, uc = self.c, self.unconditional_conditioning
+            if isinstance(c, dict):
+                assert isinstance(uc, dict)
+                c_in = dict()
+                for k in c:
+                    if isinstance(c[k], list):
+                        c_in[k] = [torch.cat([uc[k][i], c[k][i]]) for i in range(len(c[k]))]
+                    else:
+                        c_in[k] = torch.cat([uc[k], c[k]])
+            else:
+                c_in = {"c_crossattn": [torch.cat([uc, c])]}
+            self._c_in = c_in
+        return self._c_in
+
+    def apply_model(self, x, t, **kwargs):
+        uc, scale = self.unconditional_conditioning, self.unconditional_guidance_scale
+        if uc is None or scale == 1.:
+            return self.compviz_model(x, t, self.c)
+        x_in = torch.cat([x] * 2)
+        t_in = torch.cat([t] * 2)
+        e_t_uncond, e_t = self.compviz_model(x_in, t_in, cond=self._cat_cond()).chunk(2)
+        return e_t_uncond + scale * (e_t - e_t_uncond)
+
+    def forward(self, *args, **kwargs):
+        return self.apply_model(*args, **kwargs)
+
+
+def to_d(x, sigma, denoised):
+    return (x - denoised) / append_dims(sigma, x.ndim)
+
+
+def get_ancestral_step(sigma_from, sigma_to, eta=1.):
+    if not eta:
+        return sigma_to, 0.
+    sigma_up = min(sigma_to, eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5)
+    sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
+    return sigma_down, sigma_up
+
+
+def default_noise_sampler(x):
+    return lambda sigma, sigma_next: torch.randn_like(x)
+
+
+@torch.no_grad()
+def sample_euler(model, x, sigmas, extra_args=None, callback=None, disable=None, s_churn=0., s_tmin=0., s_tmax=float('inf'),
+                 s_noise=1.):
+    """sampling.py:118-143 (Algorithm 2 of Karras et al. 2022), including the per-step randn_like draw
+    that keeps the global RNG stream aligned with the reference (:128)."""
+    extra_args = {} if extra_args is None else extra_args
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        gamma = min(s_churn / (len(sigmas) - 1), 2 ** 0.5 - 1) if s_tmin <= sigmas[i] <= s_tmax else 0.
+        eps = torch.randn_like(x) * s_noise
+        sigma_hat = sigmas[i] * (gamma + 1)
+        if gamma > 0:
+            x = x + eps * (sigma_hat ** 2 - sigmas[i] ** 2) ** 0.5
+        denoised = model(x, sigma_hat * s_in, **extra_args)
+        d = to_d(x, sigma_hat, denoised)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
+        dt = sigmas[i + 1] - sigma_hat
+        x = x + d * dt
+    return x
+
+
+@torch.no_grad()
+def sample_euler_ancestral(model, x, sigmas, extra_args=None, callback=None, disable=None, eta=1., s_noise=1., noise_sampler=None):
+    """sampling.py:147-163."""
+    extra_args = {} if extra_args is None else extra_args
+    noise_sampler = default_noise_sampler(x) if noise_sampler is None else noise_sampler
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta=eta)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        d = to_d(x, sigmas[i], denoised)
+        dt = sigma_down - sigmas[i]
+        x = x + d * dt
+        if sigmas[i + 1] > 0:
+            x = x + noise_sampler(sigmas[i], sigmas[i + 1]) * s_noise * sigma_up
+    return x
+
+
+class KDiffusionSamplerBase(object):
+    """k_diffusion_samplers.py:63-296.  `model` is a LatentDiffusion-like object exposing
+    `apply_model(x, t, cond)`, `alphas_cumprod`, `num_timesteps` and `device`."""
+
+    def __init__(self, model, sigma_min=0.0316386, sigma_max=14.5521805, beta_d=19.9, beta_min=0.1, eps_s=1e-3):
+        self.ldm_model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        assert model.alphas_cumprod.shape[0] == self.ddpm_num_timesteps, 'alphas have to be defined for each timestep'
+        self.sigma_min, self.sigma_max = sigma_min, sigma_max
+        self.beta_d, self.beta_min, self.eps_s = beta_d, beta_min, eps_s
+        self.device = model.device
+        self.alphas_cumprod = model.alphas_cumprod.clone().detach().to(torch.float32).to(self.device)
+        self.sqrt_alphas_cumprod = self.alphas_cumprod.sqrt()
+        self.sqrt_one_minus_alphas_cumprod = (1. - self.alphas_cumprod).sqrt()
+        self.noise_sampler = None
+        self.callback = None
+
+    def compute_sigmas(self, n: int):
+        return None
+
+    @torch.no_grad()
+    def _sample_common_prep(self, S, batch_size, shape, conditioning=None, x0=None, unconditional_guidance_scale=1.,
+                            unconditional_conditioning=None, **kwargs):
+        C, H, W = shape
+        size = (batch_size, C, H, W)
+        # the reference ignores x_T for k-diffusion samplers and draws randn unless x0 is given (:165-171)
+        self.x = torch.randn(size, device=self.device) if x0 is None else x0
+        self.compviz_wrapper_model = CompVisDenoiser(self.ldm_model, False).to(self.device)
+        self.ldm_wrapper_model = LDMWrapperForKDiffusion(self.compviz_wrapper_model, conditioning, unconditional_conditioning,
+                                                         unconditional_guidance_scale)
+        self.sigmas = self.compute_sigmas(S)
+        if "denoising_steps" in kwargs:  # partial denoising (img2img), :188-194
+            t = kwargs["denoising_steps"]
+            self.sigmas = self.sigmas[-(t + 1):]
+            assert self.sigmas.shape[0] == t + 1
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, x0=None, x_T=None, eta=0., verbose=True,
+               unconditional_guidance_scale=1., unconditional_conditioning=None, **kwargs):
+        self.callback = None  # the reference accepts `callback` but never forwards it to k-diffusion (:307)
+        self._sample_common_prep(S=S, batch_size=batch_size, shape=shape, conditioning=conditioning, x0=x0,
+                                 unconditional_guidance_scale=unconditional_guidance_scale,
+                                 unconditional_conditioning=unconditional_conditioning, **kwargs)
+        return self.do_sample()
+
+    @torch.no_grad()
+    def do_sample(self):
+        return self.x, None
+
+    @torch.no_grad()
+    def stochastic_encode(self, x0, t, sampling_steps, noise=None):
+        """k_diffusion_samplers.py:255-296: forward-diffuse x0 to DDPM step t*1000/sampling_steps."""
+        if noise is None:
+            noise = torch.randn_like(x0)
+        t = (t * 1000.0 / sampling_steps).long()
+        ex = lambda a: a.gather(-1, t).reshape(t.shape[0], *((1,) * (x0.ndim - 1)))
+        return ex(self.sqrt_alphas_cumprod) * x0 + ex(self.sqrt_one_minus_alphas_cumprod) * noise
+
+
+class EulerSampler(KDiffusionSamplerBase):
+    @torch.no_grad()
+    def compute_sigmas(self, n):
+        return self.compviz_wrapper_model.get_sigmas(n).to(self.device)
+
+    @torch.no_grad()
+    def do_sample(self):
+        return sample_euler(self.ldm_wrapper_model, self.x, self.sigmas), None
+
+
+class EulerAncestralSampler(KDiffusionSamplerBase):
+    @torch.no_grad()
+    def compute_sigmas(self, n):
+        return self.compviz_wrapper_model.get_sigmas(n).to(self.device)
+
+    @torch.no_grad()
+    def do_sample(self):
+        return sample_euler_ancestral(self.ldm_wrapper_model, self.x, self.sigmas, noise_sampler=self.noise_sampler), None
+
+
+def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=False):
+    """util.py:46-60 ('uniform')."""
+    if ddim_discr_method != 'uniform':
+        raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
+    c = num_ddpm_timesteps // num_ddim_timesteps
+    return np.asarray(list(range(0, num_ddpm_timesteps, c))) + 1
+
+
+class DDIMSampler(object):
+    """ddim.py (eta = 0 as the img2img driver uses it): make_schedule :38-75, stochastic_encode :615-654,
+    decode :657-676, p_sample_ddim :530-612."""
+
+    def __init__(self, model, schedule="linear", **kwargs):
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=False):
+        assert ddim_eta == 0., "only the deterministic (eta = 0) DDIM of the img2img driver is restated"
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps)
+        acp = self.model.alphas_cumprod.detach().float().cpu()
+        assert acp.shape[0] == self.ddpm_num_timesteps
+        dev = self.model.device
+        self.ddim_alphas = acp[self.ddim_timesteps].to(dev)
+        self.ddim_alphas_prev = torch.cat([acp[:1], acp[self.ddim_timesteps[:-1]]]).to(dev)
+        self.ddim_sqrt_one_minus_alphas = (1. - self.ddim_alphas).sqrt()
+        self.ddim_sigmas = torch.zeros_like(self.ddim_alphas)
+
+    @torch.no_grad()
+    def stochastic_encode(self, x0, t, use_original_steps=False, noise=None):
+        assert not use_original_steps
+        if noise is None:
+            noise = torch.randn_like(x0)
+        ex = lambda a: a.gather(-1, t).reshape(t.shape[0], *((1,) * (x0.ndim - 1)))
+        return ex(self.ddim_alphas.sqrt()) * x0 + ex(self.ddim_sqrt_one_minus_alphas) * noise
+
+    @torch.no_grad()
+    def p_sample_ddim(self, x, c, t, index, unconditional_guidance_scale=1., unconditional_conditioning=None):
+        if unconditional_conditioning is None or unconditional_guidance_scale == 1.:
+            e_t = self.model.apply_model(x, t, c)
+        else:
+            x_in = torch.cat([x] * 2)
+            t_in = torch.cat([t] * 2)
+            c_in = self._c_in if getattr(self, "_c_in", None) is not None else torch.cat([unconditional_conditioning, c])
+            e_t_uncond, e_t = self.model.apply_model(x_in, t_in, c_in).chunk(2)
+            e_t = e_t_uncond + unconditional_guidance_scale * (e_t - e_t_uncond)
+        a_t, a_prev = self.ddim_alphas[index], self.ddim_alphas_prev[index]
+        pred_x0 = (x - self.ddim_sqrt_one_minus_alphas[index] * e_t) / a_t.sqrt()
+        dir_xt = (1. - a_prev).sqrt() * e_t
+        return a_prev.sqrt() * pred_x0 + dir_xt, pred_x0
+
+    @torch.no_grad()
+    def decode(self, x_latent, cond, t_start, unconditional_guidance_scale=1.0, unconditional_conditioning=None,
+               use_original_steps=False, callback=None):
+        assert not use_original_steps
+        timesteps = self.ddim_timesteps[:t_start]
+        time_range = np.flip(timesteps)
+        total_steps = timesteps.shape[0]
+        # one concatenated conditioning for the whole decode (K/V cache friendly); same values as ddim.py:553
+        self._c_in = None
+        if unconditional_conditioning is not None and unconditional_guidance_scale != 1. and torch.is_tensor(cond):
+            self._c_in = torch.cat([unconditional_conditioning, cond])
+        x_dec = x_latent
+        for i, step in enumerate(time_range):
+            index = total_steps - i - 1
+            ts = torch.full((x_latent.shape[0],), int(step), device=x_latent.device, dtype=torch.long)
+            x_dec, _ = self.p_sample_ddim(x_dec, cond, ts, index=index, unconditional_guidance_scale=unconditional_guidance_scale,
+                                          unconditional_conditioning=unconditional_conditioning)
+            if callback:
+                callback(i)
+        self._c_in = None
+        return x_dec

@@ -1,0 +1,315 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point (through cremage_amd.ops -> ctypes ->
+libcrg_hip.so) against a plain PyTorch fp32 CPU evaluation of the same op on the same seeded inputs.
+
+Tolerances (stated per dtype):
+  bf16 kernels     : inputs are rounded to bf16 first and the reference is evaluated on those rounded
+                     values in fp32, so the remaining error is fp32-accumulate order + one bf16 output
+                     rounding: rel-L2 <= 6e-3, max-abs <= 2^-7 * max|ref| (+ small abs floor).
+  fp32-class (x3)  : split-bf16 operands carry ~2^-17 relative error each: rel-L2 <= 5e-5.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def check(got, ref, dtype, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what
+    rel = ((got - ref).norm() / ref.norm().clamp_min(1e-20)).item()
+    mx = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    if dtype == BF:
+        assert rel < 6e-3 and mx < scale * 2 ** -6 + 1e-3, (what, rel, mx, scale)
+    else:
+        assert rel < 5e-5 and mx < scale * 1e-4 + 1e-5, (what, rel, mx, scale)
+
+
+def q(x, dtype):
+    """round to the kernel's storage dtype and come back to fp32 (reference sees what the kernel sees)"""
+    return x.to(dtype).float()
+
+
+def nhwc(x, dtype):
+    return x.to(_dev()).to(dtype).contiguous(memory_format=torch.channels_last)
+
+
+DTYPES = [BF, torch.float32]
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 160, 64), (300, 320, 328), (77, 128, 768), (8, 1280, 320), (1000, 200, 72), (130, 36, 40)])
+def test_linear_shapes(dtype, M, N, K):
+    from cremage_amd import ops
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = F.linear(q(x, dtype), q(w, BF) if dtype == BF else w, b) + q(r, dtype)
+    got = ops.linear(x.to(_dev()).to(dtype), w.to(_dev()), b.to(_dev()), residual=r.to(_dev()).to(dtype))
+    check(got, ref, dtype, f"linear {M}x{N}x{K}")
+    ref2 = F.silu(F.linear(q(x, dtype), q(w, BF) if dtype == BF else w, b))
+    got2 = ops.linear(x.to(_dev()).to(dtype), w.to(_dev()), b.to(_dev()), act="silu")
+    check(got2, ref2, dtype, "linear+silu")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_batched_tokens_and_f32_out(dtype):
+    from cremage_amd import ops
+    x, w = rnd(2, 50, 96, seed=5), rnd(128, 96, seed=6, scale=0.1)
+    ref = F.linear(q(x, dtype), q(w, BF) if dtype == BF else w)
+    got = ops.linear(x.to(_dev()).to(dtype), w.to(_dev()), out_dtype=torch.float32)
+    assert got.dtype == torch.float32 and got.shape == (2, 50, 128)
+    check(got, ref, torch.float32 if dtype != BF else BF, "linear f32 out")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C", [(60, 64), (257, 320)])
+def test_geglu(dtype, M, C):
+    from cremage_amd import ops
+    x, w, b = rnd(M, C, seed=7), rnd(8 * C, C, seed=8, scale=C ** -0.5), rnd(8 * C, seed=9, scale=0.1)
+    o = F.linear(q(x, dtype), q(w, BF) if dtype == BF else w, b)
+    a, g = o.chunk(2, dim=-1)
+    ref = a * F.gelu(g)
+    got = ops.linear(x.to(_dev()).to(dtype), w.to(_dev()), b.to(_dev()), act="geglu")
+    check(got, ref, dtype, "geglu")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T", [77, 154, 64, 1])
+def test_linear_transposed(dtype, T):
+    from cremage_amd import ops
+    x, w, b = rnd(2, T, 96, seed=10), rnd(128, 96, seed=11, scale=0.1), rnd(128, seed=12)
+    ref = (F.linear(q(x, dtype), q(w, BF) if dtype == BF else w, b)).transpose(1, 2)
+    got = ops.linear_transposed(x.to(_dev()).to(dtype), w.to(_dev()), b.to(_dev()))
+    assert got.shape[-1] == (T + 7) // 8 * 8
+    check(got[:, :, :T], ref, dtype, "linear_transposed")
+    assert (got[:, :, T:] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------ conv
+def conv_ref(x, w, b, dtype, stride=1, pad=(1, 1, 1, 1), up=False, x2=None, cvec=None, res=None):
+    xx = q(x, dtype)
+    if x2 is not None:
+        xx = torch.cat([xx, q(x2, dtype)], dim=1)
+    if up:
+        xx = F.interpolate(xx, scale_factor=2, mode="nearest")
+    pt, pl, pb, pr = pad
+    xx = F.pad(xx, (pl, pr, pt, pb))
+    y = F.conv2d(xx, q(w, BF) if dtype == BF else w, b, stride=stride)
+    if cvec is not None:
+        y = y + cvec[:, :, None, None]
+    if res is not None:
+        y = y + q(res, dtype)
+    return y
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ["s1", "s2", "asym", "up", "cat", "cat1x1", "fused", "odd"])
+def test_conv2d(dtype, case):
+    from cremage_amd import ops
+    N, C, Co, H, W = 2, 64, 96, 10, 12
+    kw = {}
+    rk = {}
+    ks = 3
+    x2 = None
+    if case == "s2":
+        kw["stride"] = rk["stride"] = 2
+    if case == "asym":
+        kw["stride"] = rk["stride"] = 2
+        kw["padding"] = rk["pad"] = (0, 0, 1, 1)
+    if case == "up":
+        kw["upsample2x"] = rk["up"] = True
+    if case in ("cat", "cat1x1"):
+        x2 = rnd(N, 32, H, W, seed=21)
+        if case == "cat1x1":
+            ks = 1
+            kw["padding"], rk["pad"] = 0, (0, 0, 0, 0)
+    if case == "odd":
+        N, C, Co, H, W = 1, 40, 72, 7, 5
+    Cin = C + (x2.shape[1] if x2 is not None else 0)
+    x, w, b = rnd(N, C, H, W, seed=20), rnd(Co, Cin, ks, ks, seed=22, scale=(Cin * ks * ks) ** -0.5), rnd(Co, seed=23)
+    cvec = res = None
+    if case == "fused":
+        cvec = rnd(N, Co, seed=24)
+    ref = conv_ref(x, w, b, dtype, x2=x2, cvec=cvec, **rk)
+    if case == "fused":
+        res = rnd(*ref.shape, seed=25)
+        ref = ref + q(res, dtype)
+    got = ops.conv2d(nhwc(x, dtype), w.to(_dev()), b.to(_dev()), x2=nhwc(x2, dtype) if x2 is not None else None,
+                     cvec=cvec.to(_dev()) if cvec is not None else None, residual=nhwc(res, dtype) if res is not None else None, **kw)
+    check(got, ref, dtype, "conv " + case)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_unet_shapes(dtype):
+    """production channel counts at small spatial size (tile tails in both M and N)"""
+    from cremage_amd import ops
+    for (ci, co, hw) in [(320, 320, 8), (640, 1280, 4), (960, 640, 6)]:
+        x, w, b = rnd(2, ci, hw, hw, seed=30), rnd(co, ci, 3, 3, seed=31, scale=(9 * ci) ** -0.5), rnd(co, seed=32)
+        check(ops.conv2d(nhwc(x, dtype), w.to(_dev()), b.to(_dev())), conv_ref(x, w, b, dtype), dtype, f"conv {ci}->{co}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ci,co,ks", [(4, 64, 3), (4, 320, 3), (3, 128, 3), (320, 4, 3), (128, 3, 3), (64, 8, 3), (8, 8, 1), (4, 4, 1)])
+def test_conv_small(dtype, ci, co, ks):
+    from cremage_amd import ops
+    x, w, b = rnd(2, ci, 9, 7, seed=40), rnd(co, ci, ks, ks, seed=41, scale=(ci * ks * ks) ** -0.5), rnd(co, seed=42)
+    ref = F.conv2d(q(x, dtype), w, b, padding=ks // 2)
+    got = ops.conv2d(nhwc(x, dtype), w.to(_dev()), b.to(_dev()), padding=ks // 2)
+    check(got, ref, dtype, f"conv_small {ci}->{co} k{ks}")
+
+
+# ------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,hw,eps", [(64, 8, 1e-5), (320, 12, 1e-5), (128, 33, 1e-6), (1280, 4, 1e-5), (32, 16, 1e-6)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_group_norm(dtype, C, hw, eps, silu):
+    from cremage_amd import ops
+    x = rnd(2, C, hw, hw, seed=50, scale=2.0) + 3.0  # large mean: exercises the shifted statistics
+    g, b = 1 + 0.1 * rnd(C, seed=51), 0.1 * rnd(C, seed=52)
+    ref = F.group_norm(q(x, dtype), 32, g, b, eps)
+    if silu:
+        ref = F.silu(ref)
+    got = ops.group_norm(nhwc(x, dtype), g.to(_dev()), b.to(_dev()), 32, eps, silu=silu)
+    check(got, ref, dtype, "group_norm")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_group_norm_concat(dtype):
+    from cremage_amd import ops
+    x1, x2 = rnd(2, 320, 6, 6, seed=53), rnd(2, 640, 6, 6, seed=54) * 2 + 1
+    g, b = 1 + 0.1 * rnd(960, seed=55), 0.1 * rnd(960, seed=56)
+    ref = F.silu(F.group_norm(torch.cat([q(x1, dtype), q(x2, dtype)], 1), 32, g, b, 1e-5))
+    got = ops.group_norm(nhwc(x1, dtype), g.to(_dev()), b.to(_dev()), 32, 1e-5, silu=True, x2=nhwc(x2, dtype))
+    check(got, ref, dtype, "group_norm concat")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dim", [64, 320, 640, 1280])
+def test_layer_norm(dtype, dim):
+    from cremage_amd import ops
+    x = rnd(2, 37, dim, seed=60) + 0.5
+    g, b = 1 + 0.1 * rnd(dim, seed=61), 0.1 * rnd(dim, seed=62)
+    ref = F.layer_norm(q(x, dtype), (dim,), g, b, 1e-5)
+    got = ops.layer_norm(x.to(_dev()).to(dtype), g.to(_dev()), b.to(_dev()), 1e-5)
+    check(got, ref, dtype, "layer_norm")
+
+
+def test_softmax_rows():
+    from cremage_amd import ops
+    x = rnd(3, 50, 80, seed=63, scale=3.0)
+    got = ops.softmax_rows_(x.clone().to(_dev()), 77, 0.3)
+    ref = torch.softmax(x[..., :77] * 0.3, dim=-1)
+    check(got[..., :77], ref, torch.float32, "softmax_rows")
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attn_ref(qq, kk, vv, heads, scale):
+    B, Nq, C = qq.shape
+    d = C // heads
+    sp = lambda t: t.reshape(B, t.shape[1], heads, d).permute(0, 2, 1, 3)
+    s = torch.einsum("bhid,bhjd->bhij", sp(qq), sp(kk)) * scale
+    o = torch.einsum("bhij,bhjd->bhid", s.softmax(-1), sp(vv))
+    return o.permute(0, 2, 1, 3).reshape(B, Nq, C)
+
+
+@pytest.mark.parametrize("heads,d,Nq,Nk", [(8, 40, 200, 77), (8, 40, 256, 256), (8, 80, 100, 154), (8, 160, 64, 64), (2, 64, 130, 81),
+                                           (4, 8, 33, 5), (4, 16, 64, 200), (2, 32, 700, 1000), (1, 128, 40, 90), (8, 40, 1024, 1024)])
+def test_flash_attention(heads, d, Nq, Nk):
+    from cremage_amd import ops
+    C = heads * d
+    qq, kk, vv = rnd(2, Nq, C, seed=70), rnd(2, Nk, C, seed=71), rnd(2, Nk, C, seed=72)
+    ld = (Nk + 7) // 8 * 8
+    vt = torch.zeros(2, C, ld)
+    vt[:, :, :Nk] = vv.transpose(1, 2)
+    vt[:, :, Nk:] = float("nan")  # pad columns must never leak into the result
+    ref = attn_ref(q(qq, BF), q(kk, BF), q(vv, BF), heads, d ** -0.5)
+    got = ops.attention(qq.to(_dev()).to(BF), kk.to(_dev()).to(BF), vt.to(_dev()).to(BF), heads, Nk, d ** -0.5)
+    # P is rounded to bf16 before PV: allow the corresponding extra error
+    got, ref = got.float().cpu(), ref
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert torch.isfinite(got).all() and rel < 1e-2, (rel, heads, d, Nq, Nk)
+
+
+def test_flash_attention_spiky_rows():
+    """online-softmax rescale path: one key dominates late in the sequence (guide rule 26)"""
+    from cremage_amd import ops
+    heads, d, Nq, Nk = 2, 64, 64, 300
+    C = heads * d
+    qq, kk, vv = rnd(1, Nq, C, seed=73), rnd(1, Nk, C, seed=74), rnd(1, Nk, C, seed=75)
+    kk[0, 250] = qq[0, 3] * 4.0   # query 3 (and correlated rows) jump to a new max at key tile 3
+    kk[0, 70] = qq[0, 9] * 6.0
+    vt = vv.transpose(1, 2).contiguous()
+    vt = F.pad(vt, (0, (-Nk) % 8))
+    ref = attn_ref(q(qq, BF), q(kk, BF), q(vv, BF), heads, d ** -0.5)
+    got = ops.attention(qq.to(_dev()).to(BF), kk.to(_dev()).to(BF), vt.to(_dev()).to(BF), heads, Nk, d ** -0.5).float().cpu()
+    assert ((got - ref).norm() / ref.norm()).item() < 1e-2
+
+
+@pytest.mark.parametrize("dtype,heads,d", [(torch.float32, 4, 32), (torch.float32, 8, 40), (BF, 1, 512), (torch.float32, 1, 512)])
+def test_unfused_attention(dtype, heads, d):
+    from cremage_amd import ops
+    C, Nq, Nk = heads * d, 70, 77
+    qq, kk, vv = rnd(2, Nq, C, seed=76), rnd(2, Nk, C, seed=77), rnd(2, Nk, C, seed=78)
+    vt = F.pad(vv.transpose(1, 2), (0, (-Nk) % 8)).contiguous()
+    ref = attn_ref(q(qq, dtype), q(kk, dtype), q(vv, dtype), heads, d ** -0.5)
+    got = ops.attention(qq.to(_dev()).to(dtype), kk.to(_dev()).to(dtype), vt.to(_dev()).to(dtype), heads, Nk, d ** -0.5).float().cpu()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < (1e-2 if dtype == BF else 5e-5), rel
+
+
+# ------------------------------------------------------------------------------------------ small ops
+def test_timestep_embedding_kernel(golden):
+    from cremage_amd import ops
+    meta, g = golden("op_timestep_embedding")
+    got = ops.timestep_embedding(g["t"].to(_dev()), 320).cpu()
+    assert (got - g["e320"]).abs().max().item() < 2e-4  # sin/cos of args up to ~1e3 rad: 1 ulp of the argument
+    got = ops.timestep_embedding(g["t"].to(_dev()), 64).cpu()
+    assert (got - g["e64"]).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_and_elementwise(dtype):
+    from cremage_amd import ops
+    x = rnd(2, 5, 7, 9, seed=80)
+    y = ops.nchw_to_nhwc(x.to(_dev()), dtype)
+    assert y.shape == x.shape and y.permute(0, 2, 3, 1).is_contiguous()
+    check(y, q(x, dtype), torch.float32, "nchw_to_nhwc")
+    z = ops.nhwc_to_nchw(y, torch.float32)
+    assert z.is_contiguous()
+    check(z, q(x, dtype), torch.float32, "nhwc_to_nchw")
+    s = ops.silu(x.to(_dev()).to(dtype))
+    check(s, F.silu(q(x, dtype)), dtype, "silu")
+    a = ops.affine_cast(x.to(_dev()), 0.5, 0.5, torch.float32, 0.0, 1.0)
+    check(a, (x * 0.5 + 0.5).clamp(0, 1), torch.float32, "affine_cast")
+    yy = x.to(_dev()).to(dtype).clone()
+    ops.axpby_(yy, (2 * x).to(_dev()).to(dtype), 0.25, 1.0)
+    check(yy, q(x, dtype) + 0.25 * q(2 * x, dtype), dtype, "axpby")
+
+
+def test_errors_are_python_exceptions():
+    """the library never aborts: bad arguments come back as CrgError (mp/mp.py:125 has no handler)"""
+    from cremage_amd import _lib as L
+    from cremage_amd import ops
+    with pytest.raises(L.CrgError):
+        ops.linear(torch.zeros(4, 12, device=_dev(), dtype=BF), torch.zeros(8, 12, device=_dev()))  # K % 8 != 0
+    with pytest.raises(L.CrgError):
+        ops.linear(torch.zeros(4, 16), torch.zeros(8, 16))  # CPU tensors: no fallback
+    with pytest.raises(L.CrgError):
+        ops.group_norm(torch.zeros(1, 36, 4, 4, device=_dev(), dtype=BF), torch.ones(36, device=_dev()), torch.zeros(36, device=_dev()), 32, 1e-5)
