@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""bench.py - images/sec of the SD1.5 denoising path on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1], "C2"): SD1.5 txt2img 512x512, batch 4 per GPU, 20-step Euler
+ancestral, CFG 7.5 (UNet batch 8 per call), bf16 UNet, fp32-class VAE decode (pixel L-inf <= 1e-3 vs
+the fp32 CPU path), synthetic name-keyed weights and synthetic conditioning (no checkpoint / CLIP
+offline).  One "step" = one whole batch of images: 20 UNet calls + sampler arithmetic + VAE decode
+(+ the all-gather of decoded images when N > 1).  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the launch stream
+(crg_profile_begin/end) around one extra, un-timed step; `cpu_baseline` times the CPU oracle
+(oracle/ref_cpu.py, "port") on a bounded sample of the same workload on the host cores (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FLOPS_UNET_PER_SAMPLE = 803.25e9   # SD1.5 UNet call per latent sample, L=64
+FLOPS_VAE_DECODE = 2514.5e9        # SD1.5 VAE decode per image, L=64
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (C2: 4)")
+    ap.add_argument("--sampler_steps", type=int, default=20)
+    ap.add_argument("--sampler", default="euler_a")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    from cremage_amd import dist as D
+    from cremage_amd import ops, pipeline as P
+    from cremage_amd.synth import synth_input
+
+    rank, world, local = D.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    # ---- model: rank 0 materialises the synthetic weights, the others receive them over RCCL ----
+    t0 = time.time()
+    if rank == 0:
+        ldm = P.build_synthetic_ldm(device=dev, unet_dtype=torch.bfloat16, vae_dtype=torch.float32, seed=1234)
+    else:
+        from cremage_amd.ldm_hip.latent_diffusion import LatentDiffusion
+        from cremage_amd.ldm_hip.unet import UNetModel
+        from cremage_amd.ldm_hip.vae import AutoencoderKL
+        ldm = LatentDiffusion(UNetModel(**P.SD15_UNET), AutoencoderKL(P.SD15_VAE_DD, None, 4))
+        ldm.model.to(torch.bfloat16)
+        ldm = ldm.to(dev).eval()
+    bcast_bytes = D.broadcast_module_(ldm, src=0)
+    t_build = time.time() - t0
+
+    b = a.batch
+    first = rank * b  # this rank's global image indices [first, first + b)
+    c = torch.stack([synth_input(f"bench.c{first + i}", (77, 768), 7) for i in range(b)]).to(dev)
+    uc = synth_input("bench.uc", (1, 77, 768), 7).expand(b, -1, -1).contiguous().to(dev)
+    gens = [torch.Generator(device=dev).manual_seed(D.image_seed(42, first + i)) for i in range(b)]
+
+    def fresh_x0():
+        return torch.stack([torch.randn((4, 64, 64), generator=g, device=dev) for g in gens])
+
+    def noise_sampler(sigma, sigma_next):
+        return torch.stack([torch.randn((4, 64, 64), generator=g, device=dev) for g in gens])
+
+    def step():
+        images, _ = P.txt2img(ldm, c, uc, steps=a.sampler_steps, sampler=a.sampler, cfg_scale=7.5, height=512, width=512,
+                              x0=fresh_x0(), noise_sampler=noise_sampler)
+        return D.all_gather_batch(images)
+
+    for _ in range(a.warmup):
+        step()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    assert out.shape == (world * b, 3, 512, 512) and torch.isfinite(out).all()
+
+    n_images = world * b * a.steps
+    value = n_images / dt
+    flops_per_image = a.sampler_steps * 2 * FLOPS_UNET_PER_SAMPLE + FLOPS_VAE_DECODE
+    res = {
+        "metric": "images/sec SD1.5 512x512 20-step Euler ancestral (txt2img, CFG 7.5, incl. VAE decode)",
+        "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "SD1.5 txt2img 512x512, batch 4 per GPU, 20-step Euler ancestral, bf16 UNet (B=8 with CFG) + "
+                               "fp32-class (split-bf16 x3) VAE decode, synthetic name-keyed weights, synthetic conditioning",
+                   "images_per_gpu_per_step": b, "sampler": a.sampler, "sampler_steps": a.sampler_steps, "cfg_scale": 7.5,
+                   "parallelism": f"batch-sharded x{world} (weights broadcast {bcast_bytes / 1e9:.2f} GB once, images all-gathered per step)"},
+        "whole_path_mfma_frac": round(value / world * flops_per_image / (PEAK_BF16_TFLOPS * 1e12), 4),
+        "model_build_s": round(t_build, 1),
+    }
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream, one extra un-timed step ----
+    if rank == 0 and not a.no_roofline:
+        with ops.profile(local) as prof:
+            step()
+        fam = prof.result
+        dom = max(fam, key=lambda k: fam[k]["ms"])
+        f = fam[dom]
+        ach = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
+        res["roofline"] = {"kernel": {"conv": "gemm_kernel<..., CONV=true> (implicit-GEMM conv2d, MFMA 16x16x32 bf16)",
+                                      "gemm": "gemm_kernel<..., CONV=false> (MFMA GEMM)"}.get(dom, dom),
+                           "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "launches": f["launches"], "avg_launch_us": round(1e3 * f["ms"] / max(1, f["launches"]), 2),
+                           "algorithmic_gflop_per_launch": round(f["flops"] / max(1, f["launches"]) / 1e9, 3)}
+        res["kernel_families_ms_per_step"] = {k: round(v["ms"], 3) for k, v in fam.items() if v["launches"]}
+        res["kernel_families_tflops_or_gbs"] = {
+            k: (round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if k in ("gemm", "conv", "attention") else round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1))
+            for k, v in fam.items() if v["launches"] and v["ms"] > 0}
+
+    # ---- CPU baseline: the oracle ("port") on a bounded sample of the same workload ----
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import ref_cpu as R
+        usd = {k: v.detach().float().cpu() for k, v in ldm.model.diffusion_model.state_dict().items()}
+        vsd = {k: v.detach().float().cpu() for k, v in ldm.first_stage_model.state_dict().items()}
+        x = synth_input("bench.cpu.x", (2, 4, 64, 64), 1)
+        ctx = torch.cat([uc[:1].float().cpu(), c[:1].float().cpu()])
+        tt = torch.tensor([500.25, 500.25])
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            R.unet_forward(usd, P.SD15_UNET, x, tt, ctx)
+            t_unet = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            R.decode_first_stage(vsd, P.SD15_VAE_DD, x[:1])
+            t_dec = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(1.0 / (a.sampler_steps * t_unet + t_dec), 6), "unit": "images/s",
+                               "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"1 UNet call (B=2 = one image x CFG, 64x64 latent, fp32) = {t_unet:.2f} s and 1 VAE decode = "
+                                         f"{t_dec:.2f} s on the host; images/s = 1 / (20 * t_unet + t_dec)"}
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
