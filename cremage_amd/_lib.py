@@ -42,6 +42,7 @@ class ConvArgs(C.Structure):
         ("x", c_void_p), ("x2", c_void_p), ("C1", c_int), ("C2", c_int),
         ("w", c_void_p), ("w_lo", c_void_p),
         ("bias", c_void_p), ("cvec", c_void_p),
+        ("cvec_ld", c_int64),
         ("residual", c_void_p),
         ("y", c_void_p),
         ("N", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int), ("Ho", c_int), ("Wo", c_int),

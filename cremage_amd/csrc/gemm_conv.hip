@@ -28,7 +28,8 @@ struct GemmP {
   const void* res; long ldr, r_bs;
   void* y; long ldy, y_bs;
   int M, N, K, epi;
-  const float* cvec; int cvec_rows;  // cvec[(m / cvec_rows) * N + n]
+  const float* cvec; int cvec_rows; long cvec_ld;  // cvec[(m / cvec_rows) * cvec_ld + n]
+  int splits; float* slab;  // split-K: fp32 partial tiles [batch][splits][M][N], reduced by splitk_reduce_kernel
   int a_is_weight;
   // conv geometry
   const void* x2; int C1, C2, Ctot, H, W, Ho, Wo, ks, stride, pad_t, pad_l, up;
@@ -204,14 +205,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK - 1) / BK;
-  load_tile(0);
-  store_tile(0);
+  const int nk_total = (p.K + BK - 1) / BK;
+  const int sid = blockIdx.z;
+  const int kt_begin = (int)((long)nk_total * sid / p.splits);
+  const int nk = (int)((long)nk_total * (sid + 1) / p.splits);
+  load_tile(kt_begin);
+  store_tile(kt_begin & 1);
   __syncthreads();
 
   const int frow = lane & 15;
   const int fq = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt_begin; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) load_tile(kt + 1);
     const char* xs = smem + (kt & 1) * STAGE_BYTES;
@@ -247,6 +251,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   }
 
   // ---- epilogue: lane holds rows n = ..+fq*4+{0..3}, column m = ..+frow of each 16x16 tile ----
+  if (p.splits > 1) {
+    float* S = p.slab + ((long)bz * p.splits + sid) * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + frow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < WNT; ++i) {
+        const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
+        if (n + 4 <= p.N) {
+          *reinterpret_cast<f32x4*>(S + (long)m * p.N + n) = acc[i][j];
+        } else {
+          for (int e = 0; e < 4 && n + e < p.N; ++e) S[(long)m * p.N + n + e] = acc[i][j][e];
+        }
+      }
+    }
+    return;
+  }
   YT* Y = reinterpret_cast<YT*>(p.y) + (long)bz * p.y_bs;
   const YT* R = p.res ? reinterpret_cast<const YT*>(p.res) + (long)bz * p.r_bs : nullptr;
 #pragma unroll
@@ -254,7 +276,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     const int m = m0 + wm * 64 + j * 16 + frow;
     if (m >= p.M) continue;
     const float brow = (p.bias_mode == CRG_BIAS_ROW) ? p.bias[m] : 0.f;
-    const float* cv = p.cvec ? p.cvec + (long)(m / p.cvec_rows) * p.N : nullptr;
+    const float* cv = p.cvec ? p.cvec + (long)(m / p.cvec_rows) * p.cvec_ld : nullptr;
     if (p.epi == CRG_EPI_GEGLU) {
       // packed columns: [v 16 | g 16] groups; tiles (2u, 2u+1) of this wave are value / gate
       if constexpr (WNT % 2 == 0) {
@@ -336,6 +358,63 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   }
 }
 
+// Split-K second pass: y = epi(sum_s slab[s] + bias) + cvec + residual, 4 consecutive n per thread.
+template <typename YT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p) {
+  const int n4 = p.N >> 2;
+  const long total = (long)p.M * n4;
+  const int bz = blockIdx.y;
+  const float* S = p.slab + (long)bz * p.splits * p.M * p.N;
+  YT* Y = reinterpret_cast<YT*>(p.y) + (long)bz * p.y_bs;
+  const YT* R = p.res ? reinterpret_cast<const YT*>(p.res) + (long)bz * p.r_bs : nullptr;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int m = (int)(idx / n4);
+    const int n = (int)(idx - (long)m * n4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(S + (long)m * p.N + n);
+    for (int s = 1; s < p.splits; ++s) v += *reinterpret_cast<const f32x4*>(S + ((long)s * p.M + m) * p.N + n);
+    if (p.bias_mode == CRG_BIAS_COL) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    else if (p.bias_mode == CRG_BIAS_ROW) v += p.bias[m];
+    if (p.epi == CRG_EPI_SILU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = crg_silu_f(v[e]);
+    }
+    if (p.cvec) v += *reinterpret_cast<const f32x4*>(p.cvec + (long)(m / p.cvec_rows) * p.cvec_ld + n);
+    if (R) {
+      const YT* rp = R + (long)m * p.ldr + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += (float)rp[e];
+    }
+    YT* yp = Y + (long)m * p.ldy + n;
+    if ((p.ldy & 3) == 0) {
+      if constexpr (sizeof(YT) == 2) {
+        bf16x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = (bf16)v[e];
+        *reinterpret_cast<bf16x4*>(yp) = o4;
+      } else {
+        *reinterpret_cast<f32x4*>(yp) = v;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) yp[e] = (YT)v[e];
+    }
+  }
+}
+
+// Split-K factor: small-M problems (8x8 / 16x16 UNet levels, token GEMMs with few rows) launch far fewer
+// than 2 blocks per CU and stream long K; cut K so that ~512 blocks are in flight, keeping >= 8 k-tiles
+// per slice.  Costs one fp32 slab round trip + one extra launch, so only when the tile count is low.
+inline int choose_splits(const GemmP& p, int tiles, int batch) {
+  if (p.epi == CRG_EPI_GEGLU || (p.N & 3)) return 1;
+  const int nk = (p.K + BK - 1) / BK;
+  const long blocks = (long)tiles * batch;
+  if (blocks >= 384 || nk < 16) return 1;
+  int s = (int)((512 + blocks - 1) / blocks);
+  if (s > nk / 8) s = nk / 8;
+  if (s > 16) s = 16;
+  return s < 2 ? 1 : s;
+}
+
 template <int WNT, int NSPLIT, typename AT, typename YT, bool CONV>
 int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch) {
   constexpr int BN = 32 * WNT;
@@ -349,9 +428,20 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch) {
     if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", lds, hipGetErrorString(e));
     attr_set = true;
   }
-  dim3 grid(p.tiles_n * p.tiles_m, batch);
+  p.splits = choose_splits(p, p.tiles_n * p.tiles_m, batch);
+  if (p.splits > 1) {
+    p.slab = (float*)crg_scratch(ctx, (size_t)batch * p.splits * p.M * p.N * sizeof(float));
+    if (!p.slab) return crg_fail(ctx, -12, "gemm: out of scratch for %d split-K slabs", p.splits);
+  }
+  dim3 grid(p.tiles_n * p.tiles_m, batch, p.splits);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   CRG_CHECK_LAUNCH(ctx, "gemm");
+  if (p.splits > 1) {
+    const long total = (long)p.M * (p.N >> 2);
+    const int rg = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel<YT>, dim3(rg, batch), dim3(256), 0, st, p);
+    CRG_CHECK_LAUNCH(ctx, "splitk_reduce");
+  }
   return 0;
 }
 
@@ -401,7 +491,7 @@ extern "C" int crg_gemm(crg_ctx* ctx, void* stream, const crg_gemm_args* a) {
   p.res = a->residual; p.ldr = a->ldr; p.r_bs = a->r_bstride;
   p.y = a->y; p.ldy = a->ldy; p.y_bs = a->y_bstride;
   p.M = a->M; p.N = a->N; p.K = a->K; p.epi = a->epilogue;
-  p.cvec = nullptr; p.cvec_rows = 1; p.a_is_weight = a->a_is_weight;
+  p.cvec = nullptr; p.cvec_rows = 1; p.cvec_ld = 0; p.a_is_weight = a->a_is_weight;
   const double flops = 2.0 * a->M * (double)a->N * a->K * a->batch;
   const double bytes = ((double)a->M * a->K * crg_dtype_size(a->a_dtype) + (double)a->N * a->K * 2 +
                         (double)a->M * a->N * crg_dtype_size(a->y_dtype) * (a->residual ? 2 : 1)) * a->batch;
@@ -430,7 +520,7 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
   p.res = a->residual; p.ldr = a->Cout; p.r_bs = 0;
   p.y = a->y; p.ldy = a->Cout; p.y_bs = 0;
   p.M = a->N * a->Ho * a->Wo; p.N = a->Cout; p.K = a->ksize * a->ksize * Ctot; p.epi = CRG_EPI_NONE;
-  p.cvec = a->cvec; p.cvec_rows = a->Ho * a->Wo;
+  p.cvec = a->cvec; p.cvec_rows = a->Ho * a->Wo; p.cvec_ld = a->cvec_ld ? a->cvec_ld : a->Cout;
   p.H = a->H; p.W = a->W; p.Ho = a->Ho; p.Wo = a->Wo; p.ks = a->ksize; p.stride = a->stride;
   p.pad_t = a->pad_t; p.pad_l = a->pad_l; p.up = a->upsample2x;
   const double flops = 2.0 * p.M * (double)p.N * p.K;

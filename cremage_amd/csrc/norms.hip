@@ -46,7 +46,21 @@ __global__ __launch_bounds__(512) void gn_stats_kernel(const T* __restrict__ x, 
     const int Cs = second ? C2 : C1;
     const int r_begin = chunk * rows_per_chunk;
     const int r_end = min(HW, r_begin + rows_per_chunk);
-    for (int r = r_begin + rl; r < r_end; r += rpi) {
+    int r = r_begin + rl;
+    for (; r + 3 * rpi < r_end; r += 4 * rpi) {  // 4 independent 16-byte loads in flight per lane
+      crg_vec8<T> v0, v1, v2, v3;
+      v0.load(base + (long)r * Cs);
+      v1.load(base + (long)(r + rpi) * Cs);
+      v2.load(base + (long)(r + 2 * rpi) * Cs);
+      v3.load(base + (long)(r + 3 * rpi) * Cs);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d0 = v0.get(e) - sh[e], d1 = v1.get(e) - sh[e], d2 = v2.get(e) - sh[e], d3 = v3.get(e) - sh[e];
+        a1[e] += (d0 + d1) + (d2 + d3);
+        a2[e] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+    }
+    for (; r < r_end; r += rpi) {
       crg_vec8<T> v;
       v.load(base + (long)r * Cs);
 #pragma unroll
@@ -82,20 +96,31 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const T* __restrict__ x, 
   const int t = threadIdx.x;
   const int gs = C / groups;
   const int C2 = C - C1;
-  if (t < groups) {
-    const double K = (double)kbuf[n * groups + t];
+  {
+    // 8 lanes per group sum the chunk partials in fp64, then a 3-step shuffle reduction
+    const int g = t >> 3, sub = t & 7;
     double a = 0.0, b = 0.0;
-    for (int ch = 0; ch < n_chunks; ++ch) {
-      const float* pp = part + (((long)n * n_chunks + ch) * groups + t) * 2;
-      a += (double)pp[0];
-      b += (double)pp[1];
+    if (g < groups) {
+      for (int ch = sub; ch < n_chunks; ch += 8) {
+        const float* pp = part + (((long)n * n_chunks + ch) * groups + g) * 2;
+        a += (double)pp[0];
+        b += (double)pp[1];
+      }
     }
-    const double cnt = (double)HW * gs;
-    const double md = a / cnt;
-    double var = b / cnt - md * md;
-    if (var < 0.0) var = 0.0;
-    meanv[t] = (float)(K + md);
-    rstdv[t] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      a += __shfl_xor(a, o);
+      b += __shfl_xor(b, o);
+    }
+    if (g < groups && sub == 0) {
+      const double K = (double)kbuf[n * groups + g];
+      const double cnt = (double)HW * gs;
+      const double md = a / cnt;
+      double var = b / cnt - md * md;
+      if (var < 0.0) var = 0.0;
+      meanv[g] = (float)(K + md);
+      rstdv[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
   }
   __syncthreads();
   const int tpr = C >> 3;
@@ -117,7 +142,25 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const T* __restrict__ x, 
   T* yb = y + (long)n * HW * C + c0;
   const int r_begin = blockIdx.x * rows_per_block;
   const int r_end = min(HW, r_begin + rows_per_block);
-  for (int r = r_begin + rl; r < r_end; r += rpi) {
+  int r = r_begin + rl;
+  for (; r + rpi < r_end; r += 2 * rpi) {
+    crg_vec8<T> v0, v1, o0, o1;
+    v0.load(base + (long)r * Cs);
+    v1.load(base + (long)(r + rpi) * Cs);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f0 = v0.get(e) * sc[e] + sf[e], f1 = v1.get(e) * sc[e] + sf[e];
+      if (silu) {
+        f0 = crg_silu_f(f0);
+        f1 = crg_silu_f(f1);
+      }
+      o0.set(e, f0);
+      o1.set(e, f1);
+    }
+    o0.store(yb + (long)r * C);
+    o1.store(yb + (long)(r + rpi) * C);
+  }
+  for (; r < r_end; r += rpi) {
     crg_vec8<T> v, o;
     v.load(base + (long)r * Cs);
 #pragma unroll
@@ -227,10 +270,12 @@ extern "C" int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const vo
   if (!x2) C1 = C;
   CRG_REQUIRE(ctx, C1 > 0 && C1 <= C && C1 % 8 == 0 && (C - C1) % 8 == 0, "groupnorm: concat split C1=%d of C=%d unsupported", C1, C);
   CRG_REQUIRE(ctx, dtype == CRG_BF16 || dtype == CRG_F32, "groupnorm: dtype %d unsupported", dtype);
-  // rows per block: aim for >= ~1024 blocks over the chip, at least 8 rows each
-  int chunks = (HW + 63) / 64;
-  while ((long)chunks * N < 1024 && chunks < HW / 8) chunks *= 2;
-  if (chunks > HW) chunks = HW;
+  // rows per block: ~32 rows each, at most 256 chunks per sample (the apply prologue re-reduces them),
+  // and at least ~512 blocks over the chip when the image is large enough
+  int chunks = HW / 32;
+  if (chunks < 1) chunks = 1;
+  if (chunks > 256) chunks = 256;
+  while ((long)chunks * N < 512 && chunks * 8 <= HW && chunks < 256) chunks *= 2;
   if (chunks < 1) chunks = 1;
   const int rpc = (HW + chunks - 1) / chunks;
   chunks = (HW + rpc - 1) / rpc;

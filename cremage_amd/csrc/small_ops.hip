@@ -7,18 +7,19 @@ namespace {
 template <typename T>
 __device__ __forceinline__ float ldf(const T* p) { return (float)*p; }
 
-// ---- conv3x3, Cin <= 8 (conv_in): thread = (pixel, 8 output channels); weights in LDS as [tap*Cin][Cout]
-template <typename XT, typename YT>
+// ---- conv (3x3 or 1x1), Cin <= 8 (conv_in): thread = (pixel, 8 output channels); weights in LDS as
+// [tap*Cin + ci][Cout] fp32; the whole input pixel (<= 8 channels) is one vector load per tap and the 8 outputs
+// one 16-byte store.
+template <typename XT, typename YT, int CI>
 __global__ __launch_bounds__(256) void conv_small_cin_kernel(const XT* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, YT* __restrict__ y, int N, int H, int W,
-                                                             int Cin, int Cout, int ks) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];  // [ks*ks*Cin][Cout]
+                                                             int Cout, int ks) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [ks*ks*CI][Cout]
   const int taps = ks * ks, pad = ks / 2;
-  for (int i = threadIdx.x; i < taps * Cin * Cout; i += 256) {
-    // i -> (k = tap*Cin+ci, co); source [co][ci][tap]
+  for (int i = threadIdx.x; i < taps * CI * Cout; i += 256) {
     const int co = i % Cout, k = i / Cout;
-    const int tap = k / Cin, ci = k - tap * Cin;
-    wl[i] = w[((long)co * Cin + ci) * taps + tap];
+    const int tap = k / CI, ci = k - tap * CI;
+    wl[i] = w[((long)co * CI + ci) * taps + tap];
   }
   __syncthreads();
   const int cg = Cout >> 3;  // 8-channel groups
@@ -35,22 +36,42 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const XT* __restric
     for (int tap = 0; tap < taps; ++tap) {
       const int hi = ho + tap / ks - pad, wi = wo + tap % ks - pad;
       if ((unsigned)hi >= (unsigned)H || (unsigned)wi >= (unsigned)W) continue;
-      const XT* xp = x + (((long)n * H + hi) * W + wi) * Cin;
-      for (int ci = 0; ci < Cin; ++ci) {
-        const float xv = ldf(xp + ci);
-        const float* wp = wl + (tap * Cin + ci) * Cout + g * 8;
+      const XT* xp = x + (((long)n * H + hi) * W + wi) * CI;
+      float xv[CI];
+      if constexpr (CI == 4 && sizeof(XT) == 2) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(xp);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += xv * wp[e];
+        for (int c = 0; c < 4; ++c) xv[c] = (float)v[c];
+      } else if constexpr (CI == 4 && sizeof(XT) == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xp);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xv[c] = v[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < CI; ++c) xv[c] = (float)xp[c];
+      }
+#pragma unroll
+      for (int ci = 0; ci < CI; ++ci) {
+        const float* wp = wl + (tap * CI + ci) * Cout + g * 8;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[e] += xv[ci] * w0[e];
+          acc[4 + e] += xv[ci] * w1[e];
+        }
       }
     }
-    YT* yp = y + pix * Cout + g * 8;
+    crg_vec8<YT> o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) yp[e] = (YT)acc[e];
+    for (int e = 0; e < 8; ++e) o.set(e, acc[e]);
+    o.store(y + pix * Cout + g * 8);
   }
 }
 
-// ---- conv3x3, Cout <= 8 (conv_out): thread = pixel, all output channels; weights in LDS [tap][Cin][Cout]
-template <typename XT, typename YT, int CO>
+// ---- conv (3x3 or 1x1), Cout <= 8 (conv_out): LPP lanes share one output pixel, each lane walks every LPP-th
+// 8-channel chunk of Cin (consecutive lanes -> consecutive 16-byte chunks: coalesced rows), partial sums are
+// combined with a shuffle tree.  Weights in LDS as [tap][Cin][CO] fp32.
+template <typename XT, typename YT, int CO, int LPP>
 __global__ __launch_bounds__(256) void conv_small_cout_kernel(const XT* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, YT* __restrict__ y, int N, int H, int W,
                                                               int Cin, int Cout, int ks) {
@@ -63,41 +84,53 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const XT* __restri
   }
   __syncthreads();
   const long total = (long)N * H * W;
-  for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (long)gridDim.x * 256) {
-    const int wo = (int)(pix % W);
-    const int ho = (int)((pix / W) % H);
-    const int n = (int)(pix / ((long)W * H));
+  const int sub = threadIdx.x % LPP;
+  const int ppb = 256 / LPP;  // pixels per block iteration
+  for (long pix0 = (long)blockIdx.x * ppb; pix0 < total; pix0 += (long)gridDim.x * ppb) {
+    const long pix = pix0 + threadIdx.x / LPP;
+    const bool live = pix < total;
+    const long pp = live ? pix : total - 1;
+    const int wo = (int)(pp % W);
+    const int ho = (int)((pp / W) % H);
+    const int n = (int)(pp / ((long)W * H));
     float acc[CO];
 #pragma unroll
-    for (int e = 0; e < CO; ++e) acc[e] = (bias && e < Cout) ? bias[e] : 0.f;
+    for (int e = 0; e < CO; ++e) acc[e] = 0.f;
     for (int tap = 0; tap < taps; ++tap) {
       const int hi = ho + tap / ks - pad, wi = wo + tap % ks - pad;
       if ((unsigned)hi >= (unsigned)H || (unsigned)wi >= (unsigned)W) continue;
       const XT* xp = x + (((long)n * H + hi) * W + wi) * Cin;
       const float* wt = wl + tap * Cin * CO;
       if ((Cin & 7) == 0) {
-        for (int c0 = 0; c0 < Cin; c0 += 8) {
+        for (int c0 = sub * 8; c0 < Cin; c0 += LPP * 8) {
           crg_vec8<XT> v;
           v.load(xp + c0);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float xv = v.get(j);
+            const float* wp = wt + (c0 + j) * CO;
 #pragma unroll
-            for (int e = 0; e < CO; ++e) acc[e] += xv * wt[(c0 + j) * CO + e];
+            for (int e = 0; e < CO; ++e) acc[e] += xv * wp[e];
           }
         }
       } else {
-        for (int ci = 0; ci < Cin; ++ci) {
+        for (int ci = sub; ci < Cin; ci += LPP) {
           const float xv = ldf(xp + ci);
 #pragma unroll
           for (int e = 0; e < CO; ++e) acc[e] += xv * wt[ci * CO + e];
         }
       }
     }
-    YT* yp = y + pix * Cout;
 #pragma unroll
-    for (int e = 0; e < CO; ++e)
-      if (e < Cout) yp[e] = (YT)acc[e];
+    for (int o = 1; o < LPP; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < CO; ++e) acc[e] += __shfl_xor(acc[e], o);
+    if (live && sub == 0) {
+      YT* yp = y + pix * Cout;
+#pragma unroll
+      for (int e = 0; e < CO; ++e)
+        if (e < Cout) yp[e] = (YT)(acc[e] + (bias ? bias[e] : 0.f));
+    }
   }
 }
 
@@ -188,28 +221,40 @@ extern "C" int crg_conv_small(crg_ctx* ctx, void* stream, const void* x, const f
   const double bytes = (double)N * H * W * (Cin * crg_dtype_size(x_dtype) + Cout * crg_dtype_size(y_dtype));
   crg_prof_scope ps(ctx, st, CRG_K_CONV_SMALL, flops, bytes);
   int rc;
-  if (Cout <= 8) {
+  if (Cout <= 8 && (Cin > 8 || Cout <= Cin)) {
     const size_t lds = (size_t)ks * ks * Cin * 8 * sizeof(float);
     CRG_REQUIRE(ctx, lds <= 160 * 1024, "conv_small: Cin=%d too large for the LDS weight image", Cin);
     if ((Cin & 7) == 0) CRG_REQUIRE(ctx, ((uintptr_t)x & 15) == 0, "conv_small: x must be 16-byte aligned");
     rc = by_dtype2(ctx, x_dtype, y_dtype, "conv_small", [&](auto* xs, auto* ys) {
       using XT = std::remove_const_t<std::remove_pointer_t<decltype(xs)>>;
       using YT = std::remove_pointer_t<decltype(ys)>;
-      auto kern = conv_small_cout_kernel<XT, YT, 8>;
-      if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kern, dim3(grid_for((long)N * H * W)), dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cin, Cout, ks);
+      const long pixels = (long)N * H * W;
+      if (Cin >= 64) {
+        auto kern = conv_small_cout_kernel<XT, YT, 8, 8>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid_for(pixels * 8)), dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cin, Cout, ks);
+      } else {
+        auto kern = conv_small_cout_kernel<XT, YT, 8, 1>;
+        hipLaunchKernelGGL(kern, dim3(grid_for(pixels)), dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cin, Cout, ks);
+      }
       return 0;
     });
   } else {
     CRG_REQUIRE(ctx, Cout % 8 == 0, "conv_small: Cout=%d must be a multiple of 8 when Cin <= 8", Cout);
+    CRG_REQUIRE(ctx, Cin == 3 || Cin == 4 || Cin == 8, "conv_small: Cin=%d unsupported on the thin-input path (3, 4 or 8)", Cin);
     const size_t lds = (size_t)ks * ks * Cin * Cout * sizeof(float);
     CRG_REQUIRE(ctx, lds <= 160 * 1024, "conv_small: Cout=%d too large for the LDS weight image", Cout);
     rc = by_dtype2(ctx, x_dtype, y_dtype, "conv_small", [&](auto* xs, auto* ys) {
       using XT = std::remove_const_t<std::remove_pointer_t<decltype(xs)>>;
       using YT = std::remove_pointer_t<decltype(ys)>;
-      auto kern = conv_small_cin_kernel<XT, YT>;
-      if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kern, dim3(grid_for((long)N * H * W * (Cout / 8))), dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cin, Cout, ks);
+      const dim3 grid(grid_for((long)N * H * W * (Cout / 8)));
+      auto go = [&](auto kern) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cout, ks);
+      };
+      if (Cin == 3) go(conv_small_cin_kernel<XT, YT, 3>);
+      else if (Cin == 4) go(conv_small_cin_kernel<XT, YT, 4>);
+      else go(conv_small_cin_kernel<XT, YT, 8>);
       return 0;
     });
   }

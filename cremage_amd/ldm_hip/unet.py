@@ -29,6 +29,9 @@ from .nn import Conv2d, Linear, SiLU, conv_nd, linear, normalization, timestep_e
 from .transformer import SpatialTransformer, exists
 
 
+_embcat_cache = ops.TensorKeyedCache()
+
+
 class TimestepBlock(nn.Module):
     """Any module where forward() takes timestep embeddings as a second argument (openaimodel.py:62-71)."""
 
@@ -122,15 +125,13 @@ class ResBlock(TimestepBlock):
         x2 = None
         if isinstance(x, tuple):
             x, x2 = x
-        # emb_layers = SiLU -> Linear (openaimodel.py:222-228); SiLU(emb) is shared by all 22 blocks of a step
-        emb_act = getattr(emb, "_crg_silu", None)
-        if emb_act is None:
-            emb_act = ops.silu(emb)
-            try:
-                emb._crg_silu = emb_act
-            except Exception:
-                pass
-        emb_out = self.emb_layers[1](emb_act, out_dtype=torch.float32)          # [N, Cout] fp32
+        # emb_layers = SiLU -> Linear (openaimodel.py:222-228).  UNetModel.forward precomputes all 22 blocks'
+        # projections with ONE GEMM per step (the embedding is step-constant across blocks) and hands each block
+        # its [N, Cout] fp32 slice; a ResBlock used on its own computes it here.
+        pre = getattr(emb, "_crg_emb_out", None)
+        emb_out = pre.get(id(self)) if pre is not None else None
+        if emb_out is None:
+            emb_out = self.emb_layers[1](ops.silu(emb), out_dtype=torch.float32)  # [N, Cout] fp32
         h = self.in_layers[0](x, silu=True, x2=x2)                              # GN32 + SiLU (one tensor even for a pair)
         h = self.in_layers[2](h, cvec=emb_out)                                  # conv + bias + emb_out[:, :, None, None]
         h = self.out_layers[0](h, silu=True)
@@ -189,6 +190,8 @@ class UNetModel(nn.Module):
         self.use_checkpoint = use_checkpoint
         self.dtype = torch.float16 if use_fp16 else torch.float32  # kept for ControlNet's `x.type(self.dtype)` (cldm.py:52)
         self.compute_dtype: Optional[torch.dtype] = None           # None = follow the parameters / autocast
+        self._ctx_cast = None
+        self._resblocks = None
         self.num_heads = num_heads
         self.num_head_channels = num_head_channels
         self.num_heads_upsample = num_heads_upsample
@@ -265,6 +268,28 @@ class UNetModel(nn.Module):
 
         self.out = nn.Sequential(normalization(ch), SiLU(), zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
 
+    # -- per-step batched timestep-embedding projections ------------------------------
+    def _emb_projections(self, emb: torch.Tensor):
+        """All ResBlocks' `emb_layers` Linear(1280 -> Cout) as one [N, 1280] x [sum Cout, 1280]^T GEMM."""
+        blocks = self._resblocks
+        if blocks is None:
+            blocks = self._resblocks = [m for m in self.modules() if isinstance(m, ResBlock)]
+        ws = tuple(b.emb_layers[1].weight for b in blocks)
+        bs = tuple(b.emb_layers[1].bias for b in blocks)
+        hit = _embcat_cache.get(ws + bs)
+        if hit is None:
+            with torch.no_grad():
+                hit = _embcat_cache.put(ws + bs, (), (torch.cat([w.detach() for w in ws], 0).contiguous(),
+                                                      torch.cat([b.detach().float() for b in bs], 0).contiguous()))
+        wcat, bcat = hit
+        out = ops.linear(ops.silu(emb), wcat, bcat, out_dtype=torch.float32)   # [N, sum Cout]
+        table, off = {}, 0
+        for b in blocks:
+            n = b.out_channels
+            table[id(b)] = out[:, off:off + n]
+            off += n
+        return table
+
     # -- dtype policy ---------------------------------------------------------------------------
     def resolve_compute_dtype(self) -> torch.dtype:
         if self.compute_dtype is not None:
@@ -282,8 +307,14 @@ class UNetModel(nn.Module):
         t_emb = timestep_embedding(timesteps, self.model_channels, dtype=cdt)
         emb = self.time_embed[0](t_emb, act="silu")
         emb = self.time_embed[2](emb)
+        emb._crg_emb_out = self._emb_projections(emb)
         if context is not None and context.dtype != cdt:
-            context = context.to(cdt)
+            # cast once per context tensor (identity + version), so that the cross-attention K/V cache, which is
+            # keyed on the tensor it receives, keeps hitting across sampler steps
+            c = self._ctx_cast
+            if c is None or c[0] is not context or c[1] != context._version or c[2].dtype != cdt:
+                self._ctx_cast = c = (context, context._version, context.to(cdt))
+            context = c[2]
         hs = []
         h = ops.nchw_to_nhwc(x, cdt)
         for module in self.input_blocks:

@@ -389,12 +389,11 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         if residual.shape != y.shape or residual.dtype != y.dtype:
             raise L.CrgError("conv2d: residual must match the output in shape and dtype")
     if cvec is not None:
-        if cvec.dtype != torch.float32 or tuple(cvec.shape) != (n, cout):
-            raise L.CrgError("conv2d: cvec must be fp32 [N, Cout]")
-        cvec = cvec.contiguous()
+        if cvec.dtype != torch.float32 or tuple(cvec.shape) != (n, cout) or cvec.stride(1) != 1 or cvec.stride(0) % 4:
+            raise L.CrgError("conv2d: cvec must be fp32 [N, Cout] with unit column stride and 16-byte aligned rows")
     a = L.ConvArgs(x=x.data_ptr(), x2=x2.data_ptr() if x2 is not None else None, C1=c1, C2=c2, w=hi.data_ptr(),
                    w_lo=lo.data_ptr() if lo is not None else None, bias=_p(f32_vec(bias)).value, cvec=_p(cvec).value,
-                   residual=_p(residual).value, y=y.data_ptr(), N=n, H=hh, W=ww, Cout=cout, Ho=ho, Wo=wo, ksize=ks, stride=stride,
+                   cvec_ld=cvec.stride(0) if cvec is not None else 0, residual=_p(residual).value, y=y.data_ptr(), N=n, H=hh, W=ww, Cout=cout, Ho=ho, Wo=wo, ksize=ks, stride=stride,
                    pad_t=pt, pad_l=pl, upsample2x=int(upsample2x), x_dtype=_act_dt(x), y_dtype=_act_dt(y), prec=_prec(x))
     h = _h(x)
     L.check(L.load().crg_conv2d(h, _st(), C.byref(a)), h, "crg_conv2d")

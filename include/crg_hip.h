@@ -128,6 +128,7 @@ typedef struct {
   const void* x; const void* x2; int C1, C2;
   const void* w; const void* w_lo;
   const float* bias; const float* cvec;
+  int64_t cvec_ld;                  /* row stride of cvec in floats (0 = Cout) */
   const void* residual;
   void* y;
   int N, H, W, Cout, Ho, Wo;
