@@ -56,6 +56,10 @@ extern "C" int crg_ctx_create(int device, crg_ctx** out) {
   crg_ctx* c = new (std::nothrow) crg_ctx();
   if (!c) return -12;
   c->device = device;
+  if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
+    delete c;
+    return -12;
+  }
   *out = c;
   return 0;
 }
@@ -63,6 +67,7 @@ extern "C" int crg_ctx_create(int device, crg_ctx** out) {
 extern "C" void crg_ctx_destroy(crg_ctx* ctx) {
   if (!ctx) return;
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   for (auto& r : ctx->recs) {
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);

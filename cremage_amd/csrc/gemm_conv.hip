@@ -29,6 +29,7 @@ struct GemmP {
   void* y; long ldy, y_bs;
   int M, N, K, epi;
   const float* cvec; int cvec_rows; long cvec_ld;  // cvec[(m / cvec_rows) * cvec_ld + n]
+  const bf16* zero_page;    // >= 16 bytes of zeros in device memory (LDS-DMA source for padding / tails)
   int splits; float* slab;  // split-K: fp32 partial tiles [batch][splits][M][N], reduced by splitk_reduce_kernel
   int a_is_weight;
   // conv geometry
@@ -51,6 +52,117 @@ __device__ __forceinline__ bf16x8 split_hi(const crg_vec8<float>& v, bf16x8& lo)
     lo[i] = (bf16)(f - (float)h);
   }
   return hi;
+}
+
+// ---- shared epilogue: lane holds rows n = ..+fq*4+{0..3}, column m = ..+frow of each 16x16 tile ----
+template <int WNT, typename YT>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][4], int m0, int n0, int wm, int wn, int frow, int fq,
+                                              int bz, int sid) {
+  if (p.splits > 1) {
+    float* S = p.slab + ((long)bz * p.splits + sid) * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + frow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < WNT; ++i) {
+        const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
+        if (n + 4 <= p.N) {
+          *reinterpret_cast<f32x4*>(S + (long)m * p.N + n) = acc[i][j];
+        } else {
+          for (int e = 0; e < 4 && n + e < p.N; ++e) S[(long)m * p.N + n + e] = acc[i][j][e];
+        }
+      }
+    }
+    return;
+  }
+  YT* Y = reinterpret_cast<YT*>(p.y) + (long)bz * p.y_bs;
+  const YT* R = p.res ? reinterpret_cast<const YT*>(p.res) + (long)bz * p.r_bs : nullptr;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wm * 64 + j * 16 + frow;
+    if (m >= p.M) continue;
+    const float brow = (p.bias_mode == CRG_BIAS_ROW) ? p.bias[m] : 0.f;
+    const float* cv = p.cvec ? p.cvec + (long)(m / p.cvec_rows) * p.cvec_ld : nullptr;
+    if (p.epi == CRG_EPI_GEGLU) {
+      // packed columns: [v 16 | g 16] groups; tiles (2u, 2u+1) of this wave are value / gate
+      if constexpr (WNT % 2 == 0) {
+#pragma unroll
+        for (int u = 0; u < WNT / 2; ++u) {
+          const int pn = n0 + wn * (16 * WNT) + u * 32 + fq * 4;  // packed column of the value tile
+          if (pn >= p.N) continue;
+          const int jn = (n0 + wn * (16 * WNT)) / 2 + u * 16 + fq * 4;  // output column
+          f32x4 v = acc[2 * u][j], g = acc[2 * u + 1][j];
+          if (p.bias_mode == CRG_BIAS_COL) {
+            v += *reinterpret_cast<const f32x4*>(p.bias + pn);
+            g += *reinterpret_cast<const f32x4*>(p.bias + pn + 16);
+          }
+          YT out[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) out[e] = (YT)(v[e] * crg_gelu_erf_f(g[e]));
+          YT* dst = Y + (long)m * p.ldy + jn;
+          if constexpr (sizeof(YT) == 2) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(out);
+          else *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<f32x4*>(out);
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int i = 0; i < WNT; ++i) {
+      const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      const bool full = (n + 4 <= p.N);
+      if (full) {
+        if (p.bias_mode == CRG_BIAS_COL) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        else if (p.bias_mode == CRG_BIAS_ROW) v += brow;
+        if (p.epi == CRG_EPI_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = crg_silu_f(v[e]);
+        }
+        if (cv) v += *reinterpret_cast<const f32x4*>(cv + n);
+        const long yo = (long)m * p.ldy + n;
+        if (R) {
+          const YT* rp = R + (long)m * p.ldr + n;
+          if (((p.ldr | n) & 3) == 0) {
+            if constexpr (sizeof(YT) == 2) {
+              bf16x4 r4 = *reinterpret_cast<const bf16x4*>(rp);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+            } else {
+              v += *reinterpret_cast<const f32x4*>(rp);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rp[e];
+          }
+        }
+        if (((p.ldy | n) & 3) == 0) {
+          if constexpr (sizeof(YT) == 2) {
+            bf16x4 o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o4[e] = (bf16)v[e];
+            *reinterpret_cast<bf16x4*>(Y + yo) = o4;
+          } else {
+            *reinterpret_cast<f32x4*>(Y + yo) = v;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Y[yo + e] = (YT)v[e];
+        }
+      } else {
+        for (int e = 0; e < 4 && n + e < p.N; ++e) {
+          float s = v[e];
+          if (p.bias_mode == CRG_BIAS_COL) s += p.bias[n + e];
+          else if (p.bias_mode == CRG_BIAS_ROW) s += brow;
+          if (p.epi == CRG_EPI_SILU) s = crg_silu_f(s);
+          if (cv) s += cv[n + e];
+          if (R) s += (float)R[(long)m * p.ldr + n + e];
+          Y[(long)m * p.ldy + n + e] = (YT)s;
+        }
+      }
+    }
+  }
 }
 
 template <int WNT, int NSPLIT, typename AT, typename YT, bool CONV>
@@ -250,112 +362,168 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds rows n = ..+fq*4+{0..3}, column m = ..+frow of each 16x16 tile ----
-  if (p.splits > 1) {
-    float* S = p.slab + ((long)bz * p.splits + sid) * p.M * p.N;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + wm * 64 + j * 16 + frow;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int i = 0; i < WNT; ++i) {
-        const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
-        if (n + 4 <= p.N) {
-          *reinterpret_cast<f32x4*>(S + (long)m * p.N + n) = acc[i][j];
-        } else {
-          for (int e = 0; e < 4 && n + e < p.N; ++e) S[(long)m * p.N + n + e] = acc[i][j][e];
-        }
-      }
-    }
-    return;
+  gemm_epilogue<WNT, YT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// bf16 fast path: same tile / MFMA / epilogue, but BOTH operands are staged global -> LDS with
+// global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip, no ds_write): on gfx950 a ds_write_b128 costs ~13 LDS
+// cycles per wave-instruction (MI355X_MICROARCH.md §LDS), which made the register-staged kernel LDS-bound.
+// One wave-instruction writes 1 KiB = 8 rows x 128 B, lane-linear; the XOR swizzle of the 16-byte chunk is
+// applied on the per-lane SOURCE address (guide rule 21).  Out-of-image taps / tile tails read a 16-byte zero
+// page instead, which gives the zero padding for free.  k-tile t+1 is issued before the MFMAs of tile t; the
+// __syncthreads() at the end of the iteration (vmcnt(0) + barrier) retires it.
+template <int WNT, typename YT, bool CONV>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
+  constexpr int BN = 32 * WNT;
+  constexpr int XS_BYTES = BM * 128;
+  constexpr int WS_BYTES = BN * 128;
+  constexpr int STAGE_BYTES = XS_BYTES + WS_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  YT* Y = reinterpret_cast<YT*>(p.y) + (long)bz * p.y_bs;
-  const YT* R = p.res ? reinterpret_cast<const YT*>(p.res) + (long)bz * p.r_bs : nullptr;
+  const int tile_n = bid % p.tiles_n;
+  const int tile_m = bid / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int bz = blockIdx.y;
+
+  const bf16* A = reinterpret_cast<const bf16*>(p.a) + (long)bz * p.a_bs;
+  const bf16* Wp = p.w + (long)bz * p.w_bs;
+  const bf16* zpage = p.zero_page;
+
+  // this lane always stages LDS row (8*j + lane/8), physical chunk lane%8 of wave-instruction j = wave + 4q;
+  // the data it carries is logical chunk clog = (lane%8) ^ (row%8)
+  const int rsub = lane >> 3;
+  const int clog = (lane & 7) ^ rsub;
+
+  long xrow_off[4];
+  int xh[4], xw[4];
+  bool xok[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + wm * 64 + j * 16 + frow;
-    if (m >= p.M) continue;
-    const float brow = (p.bias_mode == CRG_BIAS_ROW) ? p.bias[m] : 0.f;
-    const float* cv = p.cvec ? p.cvec + (long)(m / p.cvec_rows) * p.cvec_ld : nullptr;
-    if (p.epi == CRG_EPI_GEGLU) {
-      // packed columns: [v 16 | g 16] groups; tiles (2u, 2u+1) of this wave are value / gate
-      if constexpr (WNT % 2 == 0) {
-#pragma unroll
-        for (int u = 0; u < WNT / 2; ++u) {
-          const int pn = n0 + wn * (16 * WNT) + u * 32 + fq * 4;  // packed column of the value tile
-          if (pn >= p.N) continue;
-          const int jn = (n0 + wn * (16 * WNT)) / 2 + u * 16 + fq * 4;  // output column
-          f32x4 v = acc[2 * u][j], g = acc[2 * u + 1][j];
-          if (p.bias_mode == CRG_BIAS_COL) {
-            v += *reinterpret_cast<const f32x4*>(p.bias + pn);
-            g += *reinterpret_cast<const f32x4*>(p.bias + pn + 16);
-          }
-          YT out[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) out[e] = (YT)(v[e] * crg_gelu_erf_f(g[e]));
-          YT* dst = Y + (long)m * p.ldy + jn;
-          if constexpr (sizeof(YT) == 2) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(out);
-          else *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<f32x4*>(out);
-        }
-      }
-      continue;
-    }
-#pragma unroll
-    for (int i = 0; i < WNT; ++i) {
-      const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j];
-      const bool full = (n + 4 <= p.N);
-      if (full) {
-        if (p.bias_mode == CRG_BIAS_COL) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-        else if (p.bias_mode == CRG_BIAS_ROW) v += brow;
-        if (p.epi == CRG_EPI_SILU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = crg_silu_f(v[e]);
-        }
-        if (cv) v += *reinterpret_cast<const f32x4*>(cv + n);
-        const long yo = (long)m * p.ldy + n;
-        if (R) {
-          const YT* rp = R + (long)m * p.ldr + n;
-          if (((p.ldr | n) & 3) == 0) {
-            if constexpr (sizeof(YT) == 2) {
-              bf16x4 r4 = *reinterpret_cast<const bf16x4*>(rp);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
-            } else {
-              v += *reinterpret_cast<const f32x4*>(rp);
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)rp[e];
-          }
-        }
-        if (((p.ldy | n) & 3) == 0) {
-          if constexpr (sizeof(YT) == 2) {
-            bf16x4 o4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o4[e] = (bf16)v[e];
-            *reinterpret_cast<bf16x4*>(Y + yo) = o4;
-          } else {
-            *reinterpret_cast<f32x4*>(Y + yo) = v;
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) Y[yo + e] = (YT)v[e];
-        }
-      } else {
-        for (int e = 0; e < 4 && n + e < p.N; ++e) {
-          float s = v[e];
-          if (p.bias_mode == CRG_BIAS_COL) s += p.bias[n + e];
-          else if (p.bias_mode == CRG_BIAS_ROW) s += brow;
-          if (p.epi == CRG_EPI_SILU) s = crg_silu_f(s);
-          if (cv) s += cv[n + e];
-          if (R) s += (float)R[(long)m * p.ldr + n + e];
-          Y[(long)m * p.ldy + n + e] = (YT)s;
-        }
-      }
+  for (int q = 0; q < 4; ++q) {
+    const int m = m0 + (wave + 4 * q) * 8 + rsub;
+    xok[q] = m < p.M;
+    if (CONV) {
+      const int hw = p.Ho * p.Wo;
+      const int img = m / hw;
+      const int rem = m - img * hw;
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      xrow_off[q] = (long)img * p.H * p.W;
+      xh[q] = ho * p.stride - p.pad_t;
+      xw[q] = wo * p.stride - p.pad_l;
+    } else {
+      xrow_off[q] = (long)m * p.lda;
+      xh[q] = xw[q] = 0;
     }
   }
+  bool wok[WNT];
+  long wrow_off[WNT];
+#pragma unroll
+  for (int q = 0; q < WNT; ++q) {
+    const int n = n0 + (wave + 4 * q) * 8 + rsub;
+    wok[q] = n < p.N;
+    wrow_off[q] = (long)n * p.ldw;
+  }
+
+  const int nk_total = (p.K + BK - 1) / BK;
+  const int sid = blockIdx.z;
+  const int kt_begin = (int)((long)nk_total * sid / p.splits);
+  const int nk = (int)((long)nk_total * (sid + 1) / p.splits);
+
+  // running (tap, channel) of this lane's logical chunk; advanced by 64 channels per k-tile
+  int kc = kt_begin * BK + clog * 8;
+  int tap = 0, cch = kc;
+  if (CONV) {
+    tap = kc / p.Ctot;
+    cch = kc - tap * p.Ctot;
+  }
+  const int Hv = p.up ? 2 * p.H : p.H, Wv = p.up ? 2 * p.W : p.W;
+
+  auto stage = [&](int buf) {
+    char* xs = smem + buf * STAGE_BYTES;
+    char* ws = xs + XS_BYTES;
+    const bool kok = kc < p.K;
+    if (CONV) {
+      const int kh = (p.ks == 3) ? (tap * 11) >> 5 : 0;
+      const int kw = (p.ks == 3) ? tap - kh * 3 : 0;
+      const bool second = cch >= p.C1;
+      const bf16* base = reinterpret_cast<const bf16*>(second ? p.x2 : p.a);
+      const int Cs = second ? p.C2 : p.C1;
+      const int cs = second ? cch - p.C1 : cch;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int hv = xh[q] + kh, wv = xw[q] + kw;
+        const bool ok = kok && xok[q] && (unsigned)hv < (unsigned)Hv && (unsigned)wv < (unsigned)Wv;
+        const int hs = p.up ? hv >> 1 : hv, wsrc = p.up ? wv >> 1 : wv;
+        const bf16* src = ok ? base + (xrow_off[q] + (long)hs * p.W + wsrc) * Cs + cs : zpage;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + (wave + 4 * q) * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bf16* src = (kok && xok[q]) ? A + xrow_off[q] + kc : zpage;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + (wave + 4 * q) * 1024), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < WNT; ++q) {
+      const bf16* src = (kok && wok[q]) ? Wp + wrow_off[q] + kc : zpage;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ws + (wave + 4 * q) * 1024), 16, 0, 0);
+    }
+    // advance to the next k-tile
+    kc += BK;
+    if (CONV) {
+      cch += BK;
+      while (cch >= p.Ctot) {
+        cch -= p.Ctot;
+        ++tap;
+      }
+    }
+  };
+
+  f32x4 acc[WNT][4];
+#pragma unroll
+  for (int i = 0; i < WNT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage(kt_begin & 1);
+  __syncthreads();
+
+  const int frow = lane & 15;
+  const int fq = lane >> 4;
+  for (int kt = kt_begin; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage((kt + 1) & 1);
+    const char* xs = smem + (kt & 1) * STAGE_BYTES;
+    const char* ws = xs + XS_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 xf[4], wf[WNT];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xs + lds_off(wm * 64 + j * 16 + frow, ks * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < WNT; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(ws + lds_off(wn * (16 * WNT) + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < WNT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  gemm_epilogue<WNT, YT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid);
 }
 
 // Split-K second pass: y = epi(sum_s slab[s] + bias) + cvec + residual, 4 consecutive n per thread.
@@ -421,7 +589,11 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch) {
   p.tiles_n = (p.N + BN - 1) / BN;
   p.tiles_m = (p.M + BM - 1) / BM;
   const size_t lds = 2 * NSPLIT * (BM + BN) * 128;
-  auto kern = gemm_kernel<WNT, NSPLIT, AT, YT, CONV>;
+  constexpr bool GLDS = (NSPLIT == 1) && (sizeof(AT) == 2);
+  void (*kern)(GemmP);
+  if constexpr (GLDS) kern = gemm_glds_kernel<WNT, YT, CONV>;
+  else kern = gemm_kernel<WNT, NSPLIT, AT, YT, CONV>;
+  p.zero_page = (const bf16*)ctx->zero_page;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
