@@ -31,12 +31,14 @@ struct AttnP {
 constexpr int VROW = 136;  // bytes per V^T LDS row (64 keys * 2 B + 8 pad)
 
 template <int KS, int NV>
-__global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
+__global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_kernel(AttnP p) {
   constexpr int KROW = KS * 32 + 16;  // bytes per K LDS row
   constexpr int KCH = 2 * KS;         // 16-byte chunks per K row
   constexpr int KLOADS = (64 * KCH + 255) / 256;
-  __shared__ __attribute__((aligned(16))) char Ks[64 * KROW];
-  __shared__ __attribute__((aligned(16))) char Vs[NV * 32 * VROW];
+  constexpr int KBYTES = 64 * KROW;
+  constexpr int VBYTES = NV * 32 * VROW;
+  // two stages of {K tile, V^T tile}: tile t+1 is written while tile t is being read, one barrier per tile
+  __shared__ __attribute__((aligned(16))) char smem[2 * (KBYTES + VBYTES)];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -50,6 +52,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   bf16* O = p.o + (long)b * p.Nq * p.ldo + (long)h * p.Dh;
 
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bf16 one = (bf16)1.0f;
+  const bf16x8 ones8 = {one, one, one, one, one, one, one, one};
+  // Row-sum trick: when the padded head dim has a spare V^T row (Dh < NV*32), row Dh of the V^T tile is
+  // all ones, so O^T[Dh][q] accumulates sum_k P[q][k] on the matrix core: the softmax denominator costs
+  // no VALU adds.  (Masked keys have P = 0 exactly, so the ones may cover them too.)
+  const bool ones_row = p.Dh < NV * 32;
 
   // ---- Q fragments (B operand): lane (r, hh) holds Q[q0 + r][16 s + 8 hh + j] ----
   bf16x8 qf[KS];
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // m_run in scaled (log2) units
 
   bf16x8 kreg[KLOADS], vreg[NV];
   auto prefetch = [&](int tile) {
@@ -91,11 +99,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
           for (int e = 0; e < 8; ++e)
             if (key0 + e >= p.Nk) v[e] = (bf16)0.f;
         }
+      } else if (ones_row && row == p.Dh) {
+        v = ones8;
       }
       vreg[i] = v;
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int buf) {
+    char* Ks = smem + buf * (KBYTES + VBYTES);
+    char* Vs = Ks + KBYTES;
 #pragma unroll
     for (int i = 0; i < KLOADS; ++i) {
       const int idx = t + 256 * i;
@@ -115,11 +127,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 
   const int ntiles = (p.Nk + 63) / 64;
   prefetch(0);
+  commit(0);
+  __syncthreads();
   for (int tile = 0; tile < ntiles; ++tile) {
-    __syncthreads();  // previous tile's LDS reads are done
-    commit();
-    __syncthreads();
-    if (tile + 1 < ntiles) prefetch(tile + 1);
+    const bool more = tile + 1 < ntiles;
+    if (more) prefetch(tile + 1);
+    const char* Ks = smem + (tile & 1) * (KBYTES + VBYTES);
+    const char* Vs = Ks + KBYTES;
 
     // ---- S^T = K Q^T ----
     f32x16 st[2];
@@ -133,39 +147,41 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kb], 0, 0, 0);
       }
     }
-    // ---- online softmax (base 2) ----
+    // ---- online softmax in base 2: p = exp2(s * scale_log2 - m); the max is taken on the raw scores ----
     const bool last = (tile + 1 == ntiles) && (p.Nk & 63);
-    float mx = -INFINITY;
+    if (last) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float s = st[kb][e] * p.scale_log2;
-        if (last) {
+        for (int e = 0; e < 16; ++e) {
           const int key = tile * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          if (key >= p.Nk) s = -INFINITY;
+          if (key >= p.Nk) st[kb][e] = -INFINITY;
         }
-        st[kb][e] = s;
-        mx = fmaxf(mx, s);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    }
+    float mx = fmaxf(st[0][0], st[1][0]);
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(st[0][e], st[1][e]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    if (__any(m_new != m_run)) {  // wave-uniform: rescale only when some row's running max moved (alpha == 1 otherwise)
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+      m_run = m_new;
+    }
     float rs = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pe = __builtin_amdgcn_exp2f(st[kb][e] - m_new);
+        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][e], p.scale_log2, -m_run));
         st[kb][e] = pe;
-        rs += pe;
+        if (!ones_row) rs += pe;
       }
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+    if (!ones_row) l_run += rs;
     // ---- P^T fragments straight from the accumulator registers ----
     bf16x8 pf[2][2];
 #pragma unroll
@@ -189,10 +205,26 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
           oacc[dv] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], oacc[dv], 0, 0, 0);
         }
     }
+    if (more) commit((tile + 1) & 1);
+    __syncthreads();
   }
 
   // ---- normalise and store: lane = query, registers = channels (4 consecutive per group) ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  float l_tot;
+  if (ones_row) {
+    // O^T row Dh sits in tile Dh/32 at register 4*((Dh%32)/8) of the hh == 0 half (Dh % 8 == 0)
+    const int dvl = p.Dh >> 5, regl = ((p.Dh & 31) >> 3) * 4;
+    float v = 0.f;
+#pragma unroll
+    for (int dv = 0; dv < NV; ++dv)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (dv == dvl && 4 * g == regl) v = oacc[dv][4 * g];
+    const float other = __shfl_xor(v, 32);
+    l_tot = hh == 0 ? v : other;
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 32);
+  }
   const float inv = 1.0f / l_tot;
   const int query = q0 + r;
   if (query < p.Nq) {

@@ -621,6 +621,7 @@ template <int NSPLIT, typename AT, typename YT, bool CONV>
 int launch_wnt(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch) {
   // 160-wide tiles when they divide N (all UNet widths are multiples of 320), else 128-wide.
   const bool geglu = p.epi == CRG_EPI_GEGLU;
+  if (!geglu && p.N <= 32) return launch<1, NSPLIT, AT, YT, CONV>(ctx, st, p, batch);  // conv_out-like thin outputs
   if (!geglu && p.N % 160 == 0) return launch<5, NSPLIT, AT, YT, CONV>(ctx, st, p, batch);
   return launch<4, NSPLIT, AT, YT, CONV>(ctx, st, p, batch);
 }
@@ -655,7 +656,7 @@ extern "C" int crg_gemm(crg_ctx* ctx, void* stream, const crg_gemm_args* a) {
     CRG_REQUIRE(ctx, !a->residual, "gemm: GEGLU epilogue takes no residual");
   }
   if (a->bias && a->bias_mode == CRG_BIAS_COL)
-    CRG_REQUIRE(ctx, ((uintptr_t)a->bias & 15) == 0 && a->N % 4 == 0, "gemm: column bias needs 16-byte alignment and N %% 4 == 0");
+    CRG_REQUIRE(ctx, ((uintptr_t)a->bias & 15) == 0, "gemm: column bias must be 16-byte aligned");
   GemmP p{};
   p.a = a->a; p.a_lo = a->a_lo; p.lda = a->lda; p.a_bs = a->a_bstride;
   p.w = (const bf16*)a->w; p.w_lo = (const bf16*)a->w_lo; p.ldw = a->ldw; p.w_bs = a->w_bstride;
@@ -679,7 +680,7 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
   CRG_REQUIRE(ctx, a->C1 % 8 == 0 && a->C2 % 8 == 0, "conv2d: channel counts must be multiples of 8 (C1=%d C2=%d); use crg_conv3x3_small", a->C1, a->C2);
   CRG_REQUIRE(ctx, (a->C2 == 0) == (a->x2 == nullptr), "conv2d: x2/C2 mismatch");
   CRG_REQUIRE(ctx, a->prec == CRG_PREC_BF16 || a->w_lo, "conv2d: BF16X3 needs the lo weight plane");
-  CRG_REQUIRE(ctx, a->Cout % 4 == 0, "conv2d: Cout=%d must be a multiple of 4; use crg_conv3x3_small", a->Cout);
+  CRG_REQUIRE(ctx, a->Cout % 4 == 0 || !a->cvec, "conv2d: a per-sample channel vector needs Cout %% 4 == 0 (got %d)", a->Cout);
   CRG_REQUIRE(ctx, ((uintptr_t)a->x & 15) == 0 && ((uintptr_t)a->w & 15) == 0 && ((uintptr_t)a->bias & 15) == 0 && ((uintptr_t)a->cvec & 15) == 0,
               "conv2d: pointers must be 16-byte aligned");
   const int Hv = a->upsample2x ? 2 * a->H : a->H, Wv = a->upsample2x ? 2 * a->W : a->W;

@@ -70,10 +70,37 @@ __global__ __launch_bounds__(512) void gn_stats_kernel(const T* __restrict__ x, 
         a2[e] += d * d;
       }
     }
+    // combine this lane's 8 channels by group in registers first (<= 2 groups when C/groups >= 8), so that
+    // the LDS atomics are 2-4 per lane instead of 16 on a handful of hot addresses
+    if (gid[0] == gid[7]) {
+      float b1 = 0.f, b2 = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      atomicAdd(&s1[gid[e]], a1[e]);
-      atomicAdd(&s2[gid[e]], a2[e]);
+      for (int e = 0; e < 8; ++e) {
+        b1 += a1[e];
+        b2 += a2[e];
+      }
+      atomicAdd(&s1[gid[0]], b1);
+      atomicAdd(&s2[gid[0]], b2);
+    } else if (gs >= 8) {
+      float b1 = 0.f, b2 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool first = gid[e] == gid[0];
+        b1 += first ? a1[e] : 0.f;
+        b2 += first ? a2[e] : 0.f;
+        c1 += first ? 0.f : a1[e];
+        c2 += first ? 0.f : a2[e];
+      }
+      atomicAdd(&s1[gid[0]], b1);
+      atomicAdd(&s2[gid[0]], b2);
+      atomicAdd(&s1[gid[7]], c1);
+      atomicAdd(&s2[gid[7]], c2);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        atomicAdd(&s1[gid[e]], a1[e]);
+        atomicAdd(&s2[gid[e]], a2[e]);
+      }
     }
   }
   __syncthreads();

@@ -207,6 +207,17 @@ inline int grid_for(long n) {
   return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
 
+// grid for kernels that first stage an `lds`-byte weight image per block: as many blocks as fit the chip at once
+// (256 CUs x blocks/CU limited by the 160 KiB LDS), never more than the work needs
+inline int grid_resident(long n_threads, size_t lds) {
+  long per_cu = lds ? (long)((160 * 1024) / lds) : 8;
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  long g = (n_threads + 255) / 256;
+  const long cap = 256 * per_cu;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
 }  // namespace
 
 extern "C" int crg_conv_small(crg_ctx* ctx, void* stream, const void* x, const float* w, const float* bias, void* y,
@@ -232,10 +243,10 @@ extern "C" int crg_conv_small(crg_ctx* ctx, void* stream, const void* x, const f
       if (Cin >= 64) {
         auto kern = conv_small_cout_kernel<XT, YT, 8, 8>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid_for(pixels * 8)), dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cin, Cout, ks);
+        hipLaunchKernelGGL(kern, dim3(grid_resident(pixels * 8, lds)), dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cin, Cout, ks);
       } else {
         auto kern = conv_small_cout_kernel<XT, YT, 8, 1>;
-        hipLaunchKernelGGL(kern, dim3(grid_for(pixels)), dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cin, Cout, ks);
+        hipLaunchKernelGGL(kern, dim3(grid_resident(pixels, lds)), dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cin, Cout, ks);
       }
       return 0;
     });
@@ -247,7 +258,7 @@ extern "C" int crg_conv_small(crg_ctx* ctx, void* stream, const void* x, const f
     rc = by_dtype2(ctx, x_dtype, y_dtype, "conv_small", [&](auto* xs, auto* ys) {
       using XT = std::remove_const_t<std::remove_pointer_t<decltype(xs)>>;
       using YT = std::remove_pointer_t<decltype(ys)>;
-      const dim3 grid(grid_for((long)N * H * W * (Cout / 8)));
+      const dim3 grid(grid_resident((long)N * H * W * (Cout / 8), lds));
       auto go = [&](auto kern) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cout, ks);

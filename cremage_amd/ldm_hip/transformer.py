@@ -44,6 +44,7 @@ def zero_init_module(module):
 
 # ---------------------------------------------------------------------------------------------- LoRA folding
 _merge_cache = ops.TensorKeyedCache()
+_qk_cache = ops.TensorKeyedCache()
 
 
 def _tkey(t: torch.Tensor):
@@ -177,14 +178,22 @@ class CrossAttention(nn.Module):
     def forward(self, x, context=None, mask=None, residual=None):
         if exists(mask):
             raise NotImplementedError("attention masks are never passed on the SD path (attention.py:648-652)")
-        q = ops.linear(x, _eff(self, self.to_q.weight, "q"))
         if context is None:
-            k = ops.linear(x, _eff(self, self.to_k.weight, "k"))
+            # self-attention: Q and K projections share their input -> one GEMM with the two weights stacked
+            wq, wk = _eff(self, self.to_q.weight, "q"), _eff(self, self.to_k.weight, "k")
+            wqk = _qk_cache.get((wq, wk))
+            if wqk is None:
+                with torch.no_grad():
+                    wqk = _qk_cache.put((wq, wk), (), torch.cat([wq.detach(), wk.detach()], 0).contiguous())
+            qk = ops.linear(x, wqk)
+            c = wq.shape[0]
+            q, k = qk[..., :c], qk[..., c:]
             vt = ops.linear_transposed(x, _eff(self, self.to_v.weight, "v"))
             nk, ipa = x.shape[1], None
             if self.ipa_num_tokens > 0:
                 raise NotImplementedError("ipa_num_tokens > 0 needs a context (attention.py:623-627)")
         else:
+            q = ops.linear(x, _eff(self, self.to_q.weight, "q"))
             k, vt, nk, ipa = self._project_kv(context, x.dtype)
         out = ops.attention(q, k, vt, self.heads, nk, self.scale)
         if ipa is not None:  # attention.py:660-681

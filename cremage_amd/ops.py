@@ -372,7 +372,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     hv, wv = (2 * hh, 2 * ww) if upsample2x else (hh, ww)
     ho = (hv + pt + pb - ks) // stride + 1
     wo = (wv + pl + pr - ks) // stride + 1
-    if cin <= 8 or cout <= 8:
+    if cin <= 8 or (cout <= 8 and (cin % 8 != 0 or cin < 64)):
         if stride != 1 or upsample2x or x2 is not None or cvec is not None or residual is not None or (pt, pl, pb, pr) != (ks // 2,) * 4:
             raise L.CrgError("conv2d: thin-channel convs support only stride 1, 'same' padding, no fusions")
         y = empty_image(n, cout, ho, wo, x.dtype, x.device)
@@ -419,10 +419,18 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, n_
     ld = vt.shape[-1]
     h = _h(q)
     if q.dtype == torch.bfloat16 and Dh <= 160:
-        o = torch.empty_like(q)
-        L.check(L.load().crg_attention(h, _st(), _p(q), Cc, _p(k), Cc, _p(vt), ld, _p(o), Cc, B, heads, Nq, n_keys, Dh, scale,
+        # q / k may be column slices of one fused projection output: rows keep their parent stride
+        def rows(t):
+            if t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+                t = t.contiguous()
+            return t, t.stride(1)
+        q, ldq = rows(q)
+        k, ldk = rows(k)
+        o = torch.empty((B, Nq, Cc), dtype=q.dtype, device=q.device)
+        L.check(L.load().crg_attention(h, _st(), _p(q), ldq, _p(k), ldk, _p(vt), ld, _p(o), Cc, B, heads, Nq, n_keys, Dh, scale,
                                        L.BF16), h, "crg_attention")
         return o
+    q, k = q.contiguous(), k.contiguous()
     # Unfused path: S = QK^T (fp32) -> row softmax -> PV, all on the GEMM kernels.  Serves the fp32-class
     # (BF16X3) configuration and head dims beyond the flash kernel (the VAE's single-head C=512
     # AttnBlock, model.py:185-209).
