@@ -1,0 +1,83 @@
+"""The N > 1 path on CPU: world_size-2 `gloo` processes exercise cremage_amd.dist (sharding, the flat
+parameter broadcast, the all-gather of results) and the per-rank seeding convention."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.conftest import REPO
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from cremage_amd import dist as D
+    r, w, _ = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)  # different initial weights on every rank
+    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.LayerNorm(16), torch.nn.Linear(16, 4).to(torch.bfloat16))
+    m.register_buffer("acp", torch.arange(5, dtype=torch.float32) * (rank + 1))
+    sent = D.broadcast_module_(m, src=0)
+    flat = torch.cat([p.detach().float().reshape(-1) for p in m.parameters()] + [m.acp])
+    # shard 5 images over 2 ranks, produce a per-image tensor from the per-image seed, gather
+    items = list(D.shard_range(5, rank, world))
+    imgs = torch.stack([torch.full((3, 2, 2), float(D.image_seed(42, i))) for i in items]) if rank == 0 else \
+        torch.stack([torch.full((3, 2, 2), float(D.image_seed(42, i))) for i in items] + [torch.zeros(3, 2, 2)])  # pad to equal b
+    out = D.all_gather_batch(imgs)
+    mx = D.max_over_ranks(float(rank + 1), "cpu")
+    D.barrier()
+    q.put((rank, sent, flat, items, out, mx))
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_world2_broadcast_shard_gather():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=120)
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] > 0                    # both ranks moved the same number of bytes
+    assert torch.equal(res[0][2], res[1][2])             # parameters + buffers identical after the broadcast
+    assert res[0][3] == [0, 1, 2] and res[1][3] == [3, 4]  # contiguous balanced shards
+    g = res[0][4]
+    assert g.shape == (6, 3, 2, 2) and torch.equal(res[0][4], res[1][4])
+    assert [float(g[i, 0, 0, 0]) for i in range(5)] == [42.0, 43.0, 44.0, 45.0, 46.0]  # seed + global image index
+    assert res[0][5] == res[1][5] == 2.0
+
+
+def test_shard_range_partitions_everything():
+    from cremage_amd import dist as D
+    for n in [0, 1, 7, 16, 33]:
+        for w in [1, 2, 3, 8]:
+            got = [i for r in range(w) for i in D.shard_range(n, r, w)]
+            assert got == list(range(n))
+            sizes = [len(D.shard_range(n, r, w)) for r in range(w)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_collectives_are_identity():
+    from cremage_amd import dist as D
+    x = torch.randn(3, 4)
+    assert D.all_gather_batch(x) is x
+    assert D.broadcast_parameters_([x]) == 0
+    assert D.max_over_ranks(3.5, "cpu") == 3.5
