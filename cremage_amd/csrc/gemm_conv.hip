@@ -57,7 +57,7 @@ __device__ __forceinline__ bf16x8 split_hi(const crg_vec8<float>& v, bf16x8& lo)
 // ---- shared epilogue: lane holds rows n = ..+fq*4+{0..3}, column m = ..+frow of each 16x16 tile ----
 template <int WNT, typename YT>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][4], int m0, int n0, int wm, int wn, int frow, int fq,
-                                              int bz, int sid) {
+                                              int bz, int sid, const bf16x4 (&pre)[WNT][4], bool use_pre) {
   if (p.splits > 1) {
     float* S = p.slab + ((long)bz * p.splits + sid) * p.M * p.N;
 #pragma unroll
@@ -122,7 +122,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][
         }
         if (cv) v += *reinterpret_cast<const f32x4*>(cv + n);
         const long yo = (long)m * p.ldy + n;
-        if (R) {
+        if (use_pre) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)pre[i][j][e];
+        } else if (R) {
           const YT* rp = R + (long)m * p.ldr + n;
           if (((p.ldr | n) & 3) == 0) {
             if constexpr (sizeof(YT) == 2) {
@@ -362,7 +365,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     __syncthreads();
   }
 
-  gemm_epilogue<WNT, YT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid);
+  const bf16x4 no_pre[WNT][4] = {};
+  gemm_epilogue<WNT, YT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid, no_pre, false);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -501,10 +505,26 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   stage(kt_begin & 1);
-  __syncthreads();
 
   const int frow = lane & 15;
   const int fq = lane >> 4;
+  // residual tile of this lane, fetched now so that its latency hides under the whole K loop (bf16 outputs)
+  bf16x4 rres[WNT][4];
+  const bool pre_res = sizeof(YT) == 2 && p.res && p.splits == 1 && (p.ldr & 3) == 0 && p.epi != CRG_EPI_GEGLU;
+  if (pre_res) {
+    const bf16* R = reinterpret_cast<const bf16*>(p.res) + (long)bz * p.r_bs;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + frow;
+#pragma unroll
+      for (int i = 0; i < WNT; ++i) {
+        const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
+        rres[i][j] = (m < p.M && n + 4 <= p.N) ? *reinterpret_cast<const bf16x4*>(R + (long)m * p.ldr + n) : bf16x4{0, 0, 0, 0};
+      }
+    }
+  }
+  __syncthreads();
+
   for (int kt = kt_begin; kt < nk; ++kt) {
     if (kt + 1 < nk) stage((kt + 1) & 1);
     const char* xs = smem + (kt & 1) * STAGE_BYTES;
@@ -523,7 +543,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
     }
     __syncthreads();
   }
-  gemm_epilogue<WNT, YT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid);
+  gemm_epilogue<WNT, YT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid, rres, pre_res);
 }
 
 // Split-K second pass: y = epi(sum_s slab[s] + bias) + cvec + residual, 4 consecutive n per thread.
@@ -576,7 +596,7 @@ inline int choose_splits(const GemmP& p, int tiles, int batch) {
   if (p.epi == CRG_EPI_GEGLU || (p.N & 3)) return 1;
   const int nk = (p.K + BK - 1) / BK;
   const long blocks = (long)tiles * batch;
-  if (blocks >= 384 || nk < 16) return 1;
+  if (blocks >= 256 || nk < 24) return 1;
   int s = (int)((512 + blocks - 1) / blocks);
   if (s > nk / 8) s = nk / 8;
   if (s > 16) s = 16;

@@ -71,10 +71,13 @@ class DiscreteSchedule(nn.Module):
     def sigma_to_t(self, sigma, quantize=None):
         quantize = self.quantize if quantize is None else quantize
         log_sigma = sigma.log()
-        dists = log_sigma - self.log_sigmas[:, None]
         if quantize:
+            dists = log_sigma - self.log_sigmas[:, None]
             return dists.abs().argmin(dim=0).view(sigma.shape)
-        low_idx = dists.ge(0).cumsum(dim=0).argmax(dim=0).clamp(max=self.log_sigmas.shape[0] - 2)
+        # external.py:71 writes `dists.ge(0).cumsum(dim=0).argmax(dim=0)`: the index of the last table entry
+        # <= log_sigma (0 when there is none).  log_sigmas is ascending, so that is a binary search - same
+        # integers, without the [1000, b] cumsum kernel every step.
+        low_idx = (torch.searchsorted(self.log_sigmas, log_sigma.contiguous(), right=True) - 1).clamp(min=0, max=self.log_sigmas.shape[0] - 2)
         high_idx = low_idx + 1
         low, high = self.log_sigmas[low_idx], self.log_sigmas[high_idx]
         w = (low - log_sigma) / (low - high)

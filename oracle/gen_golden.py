@@ -463,7 +463,28 @@ def g_alphas_doc():
          alphas_cumprod=np.asarray([vals[i] for i in range(1000)], dtype=np.float64))
 
 
-CASES = dict(alphas_doc=g_alphas_doc, groupnorm=g_groupnorm, timestep_embedding=g_timestep_embedding, resblock=g_resblock, updown=g_updown,
+def g_param_contract():
+    """Names and shapes of every parameter of the reference's SD1.5 UNet (plain and with two LoRA ranks + FaceID, the
+    way image_generator.py:314-320 constructs it) and of its AutoencoderKL: the load_state_dict contract."""
+    import hashlib
+
+    def digest(m):
+        items = sorted(f"{k}:{tuple(v.shape)}" for k, v in m.state_dict().items())
+        return hashlib.sha1("\n".join(items).encode()).hexdigest(), len(items)
+
+    with torch.device("meta"):
+        u = R_unet.UNetModel(**SD15_UNET)
+        ul = R_unet.UNetModel(**dict(SD15_UNET, lora_ranks=[4, 16], lora_weights=[1.0, 0.5], ipa_scale=0.7, ipa_num_tokens=4))
+        ae = AutoencoderKL(ddconfig=SD15_DD, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4)
+    du, nu = digest(u)
+    dl, nl = digest(ul)
+    da, na = digest(ae)
+    save("param_contract", dict(unet_sha1=du, unet_n=nu, unet_lora_sha1=dl, unet_lora_n=nl, vae_sha1=da, vae_n=na,
+                                unet_cfg=SD15_UNET, vae_dd=SD15_DD, lora_ranks=[4, 16], lora_weights=[1.0, 0.5], ipa_scale=0.7,
+                                ipa_num_tokens=4), dummy=np.zeros(1))
+
+
+CASES = dict(alphas_doc=g_alphas_doc, param_contract=g_param_contract, groupnorm=g_groupnorm, timestep_embedding=g_timestep_embedding, resblock=g_resblock, updown=g_updown,
              attention=g_attention, transformer=g_transformer, unet_tiny=g_unet_tiny, unet_small_sd=g_unet_small_sd,
              vae_blocks=g_vae_blocks, vae_tiny=g_vae_tiny, schedules=g_schedules, trajectories=g_trajectories)
 FULL = dict(unet_sd15_full=g_unet_sd15_full, vae_sd15_full=g_vae_sd15_full)

@@ -109,3 +109,26 @@ def test_attention_mode_registry_and_lora_names():
     for frag in ["proj_in_lora_downs.0.weight", "proj_out_lora_ups.1.weight", "attn1.q_lora_alphas.0", "attn2.v_lora_downs.1.weight",
                  "attn2.out_lora_ups.0.weight", "ff.net.0.proj_lora_downs.0.weight", "ff.net_2_lora_ups.1.weight"]:
         assert any(n.endswith(frag) for n in names), frag
+
+
+def test_full_state_dict_contract_sha1():
+    """sha1 over the sorted `name:shape` list of the reference's own SD1.5 UNet (plain, and with LoRA ranks [4, 16] +
+    FaceID tokens) and AutoencoderKL == the same digest of the HIP drop-in classes: `load_state_dict`, the 792 LoRA keys
+    (cremage/utils/sd15_weight_list_with_lora.py) and `to_k_ipa/to_v_ipa` land where the reference puts them."""
+    import hashlib
+    from cremage_amd.ldm_hip.unet import UNetModel
+    from cremage_amd.ldm_hip.vae import AutoencoderKL
+    meta, _ = load_golden("param_contract")
+
+    def digest(m):
+        items = sorted(f"{k}:{tuple(v.shape)}" for k, v in m.state_dict().items())
+        return hashlib.sha1("\n".join(items).encode()).hexdigest(), len(items)
+
+    with torch.device("meta"):
+        u = UNetModel(**meta["unet_cfg"])
+        ul = UNetModel(**dict(meta["unet_cfg"], lora_ranks=meta["lora_ranks"], lora_weights=meta["lora_weights"],
+                              ipa_scale=meta["ipa_scale"], ipa_num_tokens=meta["ipa_num_tokens"]))
+        ae = AutoencoderKL(meta["vae_dd"], None, 4)
+    assert digest(u) == (meta["unet_sha1"], meta["unet_n"])
+    assert digest(ul) == (meta["unet_lora_sha1"], meta["unet_lora_n"])
+    assert digest(ae) == (meta["vae_sha1"], meta["vae_n"])
