@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (C2: 4)")
     ap.add_argument("--sampler_steps", type=int, default=20)
     ap.add_argument("--sampler", default="euler_a")
+    ap.add_argument("--workload", default="sd15", choices=["sd15", "sdxl"],
+                    help="sd15 = BASELINE.json configs[1] (the headline metric, default); sdxl = configs[2] (SDXL 1024x1024 batch 2, "
+                         "30-step Euler EDM) as an extra, separately labelled measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -47,6 +50,8 @@ def main():
     from cremage_amd import ops, pipeline as P
     from cremage_amd.synth import synth_input
 
+    if a.workload == "sdxl":
+        return main_sdxl(a)
     rank, world, local = D.init_from_env()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
@@ -152,6 +157,66 @@ def main():
                                "cores": torch.get_num_threads(), "kind": "port",
                                "sample": f"1 UNet call (B=2 = one image x CFG, 64x64 latent, fp32) = {t_unet:.2f} s and 1 VAE decode = "
                                          f"{t_dec:.2f} s on the host; images/s = 1 / (20 * t_unet + t_dec)"}
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def main_sdxl(a):
+    """BASELINE.json configs[2]: SDXL txt2img 1024x1024 base-only, batch 2 per GPU, 30-step Euler (EDM), bf16 UNet + fp32-class VAE."""
+    from cremage_amd import dist as D
+    from cremage_amd import ops, pipeline as P
+    from cremage_amd.synth import synth_input
+    rank, world, local = D.init_from_env()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    b = 2 if a.batch == 4 else a.batch
+    steps = 30 if a.sampler_steps == 20 else a.sampler_steps
+    t0 = time.time()
+    eng = P.build_synthetic_sdxl(device=dev, fill=(rank == 0))
+    D.broadcast_module_(eng, src=0)
+    t_build = time.time() - t0
+    first = rank * b
+    c = {"crossattn": torch.stack([synth_input(f"bench.xl.c{first + i}", (77, 2048), 7) for i in range(b)]).to(dev),
+         "vector": torch.stack([synth_input(f"bench.xl.v{first + i}", (2816,), 7) for i in range(b)]).to(dev)}
+    uc = {"crossattn": synth_input("bench.xl.uc", (1, 77, 2048), 7).expand(b, -1, -1).contiguous().to(dev),
+          "vector": synth_input("bench.xl.ucv", (1, 2816), 7).expand(b, -1).contiguous().to(dev)}
+    gens = [torch.Generator(device=dev).manual_seed(D.image_seed(42, first + i)) for i in range(b)]
+
+    def step():
+        x0 = torch.stack([torch.randn((4, 128, 128), generator=g, device=dev) for g in gens])
+        images, _ = P.txt2img_sdxl(eng, c, uc, steps=steps, cfg_scale=5.0, x0=x0)
+        return D.all_gather_batch(images)
+
+    for _ in range(a.warmup):
+        step()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    assert out.shape == (world * b, 3, 1024, 1024) and torch.isfinite(out).all()
+    value = world * b * a.steps / dt
+    flops_per_image = steps * 2 * 6760e9 + 10470.4e9
+    res = {"metric": "images/sec SDXL 1024x1024 base-only 30-step Euler EDM (txt2img, CFG 5, incl. VAE decode)", "value": round(value, 4),
+           "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "SDXL txt2img 1024x1024 base-only, batch 2 per GPU, 30-step Euler EDM, bf16 UNet (B=4 with CFG) + "
+                                  "fp32-class VAE decode, synthetic weights/conditioning (BASELINE.json configs[2])",
+                      "images_per_gpu_per_step": b, "sampler_steps": steps},
+           "whole_path_mfma_frac": round(value / world * flops_per_image / (PEAK_BF16_TFLOPS * 1e12), 4), "model_build_s": round(t_build, 1)}
+    if rank == 0 and not a.no_roofline:
+        with ops.profile(local) as prof:
+            step()
+        fam = prof.result
+        res["kernel_families_ms_per_step"] = {k: round(v["ms"], 3) for k, v in fam.items() if v["launches"]}
+        res["kernel_families_tflops_or_gbs"] = {
+            k: (round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if k in ("gemm", "conv", "attention") else round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1))
+            for k, v in fam.items() if v["launches"] and v["ms"] > 0}
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

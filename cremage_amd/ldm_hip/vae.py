@@ -99,8 +99,10 @@ class AttnBlock(nn.Module):
 
 
 def make_attn(in_channels, attn_type="vanilla"):
-    assert attn_type in ["vanilla", "linear", "none"], f'attn_type {attn_type} unknown'
-    if attn_type == "vanilla":
+    # sgm adds "vanilla-xformers" / "memory-efficient-cross-attn" (sgm/modules/diffusionmodules/model.py:277-309,
+    # sd_xl_base.yaml:82): same parameters, same function -> the one HIP block
+    assert attn_type in ["vanilla", "vanilla-xformers", "linear", "none"], f'attn_type {attn_type} unknown'
+    if attn_type in ("vanilla", "vanilla-xformers"):
         return AttnBlock(in_channels)
     if attn_type == "none":
         return nn.Identity(in_channels)

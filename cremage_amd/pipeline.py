@@ -86,3 +86,44 @@ def img2img(ldm: LatentDiffusion, init_image: torch.Tensor, c: torch.Tensor, uc:
     z_enc = smp.stochastic_encode(init_latent, torch.tensor([t_enc] * b, device=init_latent.device), noise=fwd_noise)
     samples = smp.decode(z_enc, c, t_enc, unconditional_guidance_scale=cfg_scale, unconditional_conditioning=uc)
     return (decode_images(ldm, samples) if decode else None), samples
+
+
+# ---------------------------------------------------------------------------------------------- SDXL (config 3)
+SDXL_UNET = dict(adm_in_channels=2816, num_classes="sequential", use_checkpoint=True, in_channels=4, out_channels=4,
+                 model_channels=320, attention_resolutions=[4, 2], num_res_blocks=2, channel_mult=[1, 2, 4], num_head_channels=64,
+                 use_linear_in_transformer=True, transformer_depth=[1, 2, 10], context_dim=2048,
+                 spatial_transformer_attn_type="softmax-xformers")  # sd_xl_base.yaml:17-33
+SDXL_VAE_DD = dict(SD15_VAE_DD, attn_type="vanilla-xformers")       # sd_xl_base.yaml:80-92
+
+
+def build_synthetic_sdxl(unet_cfg=None, vae_dd=None, device="cuda", unet_dtype=torch.bfloat16, vae_dtype=torch.float32, seed: int = 1234,
+                         fill: bool = True):
+    """DiffusionEngine-like container with name-keyed synthetic weights (UNet fp16/bf16, VAE fp32 as the reference runs
+    them: vram_mode.py:24-28, sd_xl_base.yaml:5)."""
+    from .sgm_hip.sampling import DiffusionEngine
+    from .sgm_hip.unet import UNetModel as SgmUNet
+    unet = SgmUNet(**(unet_cfg or SDXL_UNET))
+    vae = AutoencoderKL(vae_dd or SDXL_VAE_DD, None, 4)
+    if fill:
+        synth_fill_(unet, seed, prefix="sgm_unet.")
+        synth_fill_(vae, seed, prefix="vae.")
+    eng = DiffusionEngine(unet, vae, 0.13025)
+    eng.model.to(unet_dtype)
+    eng.first_stage_model.to(vae_dtype)
+    return eng.to(device).eval()
+
+
+@torch.no_grad()
+def txt2img_sdxl(eng, c: dict, uc: dict, *, steps: int = 30, cfg_scale: float = 5.0, height: int = 1024, width: int = 1024,
+                 x0: Optional[torch.Tensor] = None, decode: bool = True):
+    """run_txt2img -> do_sample (modules/sdxl/sdxl_pipeline/sdxl_image_generator_utils.py:559-772): randn [b,4,H/8,W/8]
+    (:695), sampler(denoiser, randn, cond=c, uc=uc) (:707), decode_first_stage in fp32 (:727-734), clamp((x+1)/2, 0, 1).
+    c / uc: {"crossattn": [b,77,2048], "vector": [b,2816]}."""
+    b = c["crossattn"].shape[0]
+    if x0 is None:
+        x0 = torch.randn((b, 4, height // 8, width // 8), device=c["crossattn"].device)
+    samples = eng.sample(x0, c, uc, steps, cfg_scale)
+    if not decode:
+        return None, samples
+    x = eng.decode_first_stage(samples)
+    return ops.affine_cast(x, 0.5, 0.5, torch.float32, 0.0, 1.0), samples

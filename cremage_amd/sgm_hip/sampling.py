@@ -1,0 +1,173 @@
+"""SDXL denoiser / guider / sampler glue - stays on PyTorch (north_star), behaviour of
+modules/sdxl/sgm/modules/diffusionmodules/{denoiser.py:10-75, denoiser_scaling.py:29-37, discretizer.py:17-78,
+guiders.py:24-65, sampling.py:29-219,309-318, wrappers.py:24-34} and DiffusionEngine.decode_first_stage
+(sgm/models/diffusion.py:118-136).  Tensors here are [b, 4, L, L] latents and per-sample scalars; the per-step cost
+is the UNet call."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..samplers import append_dims, append_zero, make_beta_schedule
+
+
+class LegacyDDPMDiscretization:
+    """discretizer.py:51-78 (+ Discretization.__call__ :17-24)."""
+
+    def __init__(self, linear_start=0.00085, linear_end=0.0120, num_timesteps=1000):
+        self.num_timesteps = num_timesteps
+        betas = make_beta_schedule("linear", num_timesteps, linear_start=linear_start, linear_end=linear_end)
+        self.alphas_cumprod = np.cumprod(1.0 - betas, axis=0)
+
+    def get_sigmas(self, n, device="cpu"):
+        if n < self.num_timesteps:
+            timesteps = np.linspace(self.num_timesteps - 1, 0, n, endpoint=False).astype(int)[::-1]
+            alphas_cumprod = self.alphas_cumprod[timesteps]
+        elif n == self.num_timesteps:
+            alphas_cumprod = self.alphas_cumprod
+        else:
+            raise ValueError
+        sigmas = torch.tensor((1 - alphas_cumprod) / alphas_cumprod, dtype=torch.float32, device=device) ** 0.5
+        return torch.flip(sigmas, (0,))
+
+    def __call__(self, n, do_append_zero=True, device="cpu", flip=False):
+        sigmas = self.get_sigmas(n, device=device)
+        sigmas = append_zero(sigmas) if do_append_zero else sigmas
+        return sigmas if not flip else torch.flip(sigmas, (0,))
+
+
+class EpsScaling:
+    """denoiser_scaling.py:29-37."""
+
+    def __call__(self, sigma):
+        c_skip = torch.ones_like(sigma, device=sigma.device)
+        c_out = -sigma
+        c_in = 1 / (sigma ** 2 + 1.0) ** 0.5
+        c_noise = sigma.clone()
+        return c_skip, c_out, c_in, c_noise
+
+
+class DiscreteDenoiser(nn.Module):
+    """denoiser.py:10-75: sigma (and c_noise) quantised to the 1000-entry DDPM table; c_noise becomes the table index."""
+
+    def __init__(self, num_idx: int = 1000, quantize_c_noise: bool = True):
+        super().__init__()
+        self.scaling = EpsScaling()
+        self.discretization = LegacyDDPMDiscretization()
+        self.register_buffer("sigmas", self.discretization(num_idx, do_append_zero=False, flip=True))
+        self.quantize_c_noise = quantize_c_noise
+        self.num_idx = num_idx
+
+    def sigma_to_idx(self, sigma):
+        dists = sigma - self.sigmas[:, None]
+        return dists.abs().argmin(dim=0).view(sigma.shape)
+
+    def idx_to_sigma(self, idx):
+        return self.sigmas[idx]
+
+    def forward(self, network, input, sigma, cond: Dict, **additional_model_inputs):
+        sigma = self.idx_to_sigma(self.sigma_to_idx(sigma))
+        sigma_shape = sigma.shape
+        sigma = append_dims(sigma, input.ndim)
+        c_skip, c_out, c_in, c_noise = self.scaling(sigma)
+        c_noise = c_noise.reshape(sigma_shape)
+        if self.quantize_c_noise:
+            c_noise = self.sigma_to_idx(c_noise)
+        return network(input * c_in, c_noise, cond, **additional_model_inputs) * c_out + input * c_skip
+
+
+class VanillaCFG:
+    """guiders.py:24-65.  The concatenated conditioning is built once per (c, uc) pair and reused every step
+    (the reference re-concatenates identical tensors each step), which keeps the cross-attention K/V cache hot."""
+
+    def __init__(self, scale: float):
+        self.scale = scale
+        self._cache = None
+
+    def __call__(self, x, sigma):
+        x_u, x_c = x.chunk(2)
+        return x_u + self.scale * (x_c - x_u)
+
+    def prepare_inputs(self, x, s, c, uc):
+        k = self._cache
+        if k is None or k[0] is not c or k[1] is not uc:
+            c_out = dict()
+            for key in c:
+                if key in ["vector", "crossattn", "concat"]:
+                    c_out[key] = torch.cat((uc[key], c[key]), 0)
+                else:
+                    assert c[key] == uc[key]
+                    c_out[key] = c[key]
+            self._cache = k = (c, uc, c_out)
+        return torch.cat([x] * 2), torch.cat([s] * 2), k[2]
+
+
+class OpenAIWrapper(nn.Module):
+    """wrappers.py:24-34."""
+
+    def __init__(self, diffusion_model):
+        super().__init__()
+        self.diffusion_model = diffusion_model
+
+    def forward(self, x, t, c: dict, **kwargs):
+        if "concat" in c:
+            x = torch.cat((x, c["concat"]), dim=1)
+        return self.diffusion_model(x, timesteps=t, context=c.get("crossattn", None), y=c.get("vector", None), **kwargs)
+
+
+class EulerEDMSampler:
+    """sampling.py:29-219,309-318 with s_churn = 0 (the reference's default): Euler steps on the EDM ODE."""
+
+    def __init__(self, num_steps: int, guider: VanillaCFG, device="cuda", s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0):
+        self.num_steps = num_steps
+        self.discretization = LegacyDDPMDiscretization()
+        self.guider = guider
+        self.device = device
+        self.s_churn, self.s_tmin, self.s_tmax, self.s_noise = s_churn, s_tmin, s_tmax, s_noise
+
+    def denoise(self, x, denoiser, sigma, cond, uc):
+        denoised = denoiser(*self.guider.prepare_inputs(x, sigma, cond, uc))
+        return self.guider(denoised, sigma)
+
+    @torch.no_grad()
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None):
+        sigmas = self.discretization(self.num_steps if num_steps is None else num_steps, device=self.device)
+        uc = cond if uc is None else uc
+        x = x * torch.sqrt(1.0 + sigmas[0] ** 2.0)
+        num_sigmas = len(sigmas)
+        s_in = x.new_ones([x.shape[0]])
+        for i in range(num_sigmas - 1):
+            gamma = min(self.s_churn / (num_sigmas - 1), 2 ** 0.5 - 1) if self.s_tmin <= sigmas[i] <= self.s_tmax else 0.0
+            sigma, next_sigma = s_in * sigmas[i], s_in * sigmas[i + 1]
+            sigma_hat = sigma * (gamma + 1.0)
+            if gamma > 0:
+                eps = torch.randn_like(x) * self.s_noise
+                x = x + eps * append_dims(sigma_hat ** 2 - sigma ** 2, x.ndim) ** 0.5
+            denoised = self.denoise(x, denoiser, sigma_hat, cond, uc)
+            d = (x - denoised) / append_dims(sigma_hat, x.ndim)
+            x = x + append_dims(next_sigma - sigma_hat, x.ndim) * d
+        return x
+
+
+class DiffusionEngine(nn.Module):
+    """Minimal stand-in for sgm/models/diffusion.py:19-151: model wrapper + denoiser + first stage + scale factor."""
+
+    def __init__(self, unet: nn.Module, first_stage_model: nn.Module, scale_factor: float = 0.13025):
+        super().__init__()
+        self.model = OpenAIWrapper(unet)
+        self.denoiser = DiscreteDenoiser()
+        self.first_stage_model = first_stage_model
+        self.scale_factor = scale_factor
+
+    @torch.no_grad()
+    def decode_first_stage(self, z):
+        return self.first_stage_model.decode(1.0 / self.scale_factor * z)
+
+    @torch.no_grad()
+    def sample(self, x, cond: Dict, uc: Dict, steps: int, cfg_scale: float):
+        """do_sample, sdxl_image_generator_utils.py:695-707: sampler(denoiser, randn, cond=c, uc=uc)."""
+        smp = EulerEDMSampler(steps, VanillaCFG(cfg_scale), device=x.device)
+        return smp(lambda inp, sigma, c: self.denoiser(self.model, inp, sigma, c), x, cond=cond, uc=uc)

@@ -484,10 +484,95 @@ def g_param_contract():
                                 ipa_num_tokens=4), dummy=np.zeros(1))
 
 
+# ---------------------------------------------------------------------------- SDXL (sgm)
+
+TINY_SGM_UNET = dict(adm_in_channels=96, num_classes="sequential", use_checkpoint=False, in_channels=4, out_channels=4,
+                     model_channels=64, attention_resolutions=[2, 1], num_res_blocks=1, channel_mult=[1, 2], num_head_channels=32,
+                     use_linear_in_transformer=True, transformer_depth=[1, 2], context_dim=128,
+                     spatial_transformer_attn_type="softmax-xformers")
+SMALL_SDXL_UNET = dict(adm_in_channels=2816, num_classes="sequential", use_checkpoint=False, in_channels=4, out_channels=4,
+                       model_channels=64, attention_resolutions=[4, 2], num_res_blocks=2, channel_mult=[1, 2, 4], num_head_channels=64,
+                       use_linear_in_transformer=True, transformer_depth=[1, 2, 10], context_dim=2048,
+                       spatial_transformer_attn_type="softmax-xformers")
+SDXL_UNET = dict(SMALL_SDXL_UNET, model_channels=320)
+
+
+def _import_sgm():
+    SG = "/root/reference/modules/sdxl"
+    if SG not in sys.path:
+        sys.path.insert(0, SG)
+    for name, path in [("sgm", SG + "/sgm"), ("sgm.modules", SG + "/sgm/modules"),
+                       ("sgm.modules.diffusionmodules", SG + "/sgm/modules/diffusionmodules")]:
+        if name not in sys.modules:  # bare packages: their __init__ pull in lightning / open_clip
+            m = types.ModuleType(name)
+            m.__path__ = [path]
+            sys.modules[name] = m
+    from sgm.modules.diffusionmodules import denoiser, discretizer, guiders, openaimodel, sampling, wrappers
+    return openaimodel, denoiser, discretizer, guiders, sampling, wrappers
+
+
+def _sgm_unet_case(name, cfg, B, L, mctx, tvals):
+    SU = _import_sgm()[0]
+    m = SU.UNetModel(**cfg)
+    synth_fill_(m, SEED, prefix="sgm_unet.")
+    x = synth_input(name + ".x", (B, 4, L, L), SEED)
+    ctx = synth_input(name + ".ctx", (B, mctx, cfg["context_dim"]), SEED)
+    y = synth_input(name + ".y", (B, cfg["adm_in_channels"]), SEED)
+    t = torch.tensor(tvals, dtype=torch.float32)
+    t0 = time.time()
+    with fp32_forward():
+        out = m(x, timesteps=t, context=ctx, y=y)
+    dt = time.time() - t0
+    import hashlib
+    items = sorted(f"{k}:{tuple(v.shape)}" for k, v in m.state_dict().items())
+    save(name, dict(cfg=cfg, B=B, L=L, m=mctx, seed=SEED, prefix="sgm_unet.", n_params=sum(p.numel() for p in m.parameters()),
+                    n_keys=len(items), keys_sha1=hashlib.sha1("\n".join(items).encode()).hexdigest(), ref_cpu_seconds=dt,
+                    threads=torch.get_num_threads()), t=t, y=out)
+    return m
+
+
+def g_sgm_unet_tiny():
+    _sgm_unet_case("sgm_unet_tiny", TINY_SGM_UNET, 2, 16, 77, [10.0, 731.0])
+
+
+def g_sgm_unet_small():
+    _sgm_unet_case("sgm_unet_small_sdxl", SMALL_SDXL_UNET, 2, 16, 77, [3.0, 900.0])
+
+
+def g_sgm_unet_full():
+    _sgm_unet_case("sgm_unet_sdxl_full", SDXL_UNET, 2, 128, 77, [981.0, 981.0])
+
+
+def g_sgm_trajectory():
+    """5-step EulerEDMSampler through the reference's DiscreteDenoiser(EpsScaling, LegacyDDPMDiscretization) + VanillaCFG
+    + OpenAIWrapper + sgm UNetModel (tiny), then AutoencoderKL decode with scale_factor 0.13025."""
+    SU, DN, DZ, GD, SM, WR = _import_sgm()
+    SM.denoising_status_queue = types.SimpleNamespace(put=lambda *a, **k: None)
+    unet = SU.UNetModel(**TINY_SGM_UNET)
+    synth_fill_(unet, SEED, prefix="sgm_unet.")
+    model = WR.OpenAIWrapper(unet)
+    den = DN.DiscreteDenoiser(scaling_config={"target": "sgm.modules.diffusionmodules.denoiser_scaling.EpsScaling"}, num_idx=1000,
+                              discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"})
+    smp = SM.EulerEDMSampler(discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"},
+                             num_steps=5, guider_config={"target": "sgm.modules.diffusionmodules.guiders.VanillaCFG",
+                                                         "params": {"scale": 5.0}}, device="cpu")
+    B, L = 2, 16
+    c = {"crossattn": synth_input("sgmtraj.c", (B, 77, 128), SEED), "vector": synth_input("sgmtraj.cv", (B, 96), SEED)}
+    uc = {"crossattn": synth_input("sgmtraj.uc", (B, 77, 128), SEED), "vector": synth_input("sgmtraj.ucv", (B, 96), SEED)}
+    x0 = synth_input("sgmtraj.x0", (B, 4, L, L), SEED)
+    ae = _make_ae(TINY_DD)
+    with fp32_forward(), contextlib.redirect_stdout(open(os.devnull, "w")):
+        x = smp(lambda inp, sigma, cc: den(model, inp, sigma, cc), x0.clone(), cond=c, uc=uc)  # sdxl_image_generator_utils.py:703-707
+        img = ae.decode(x / 0.13025)
+    save("traj_sdxl_euler_edm", dict(B=B, L=L, S=5, cfg=5.0, seed=SEED, unet=TINY_SGM_UNET, dd=TINY_DD, scale_factor=0.13025),
+         sigmas=smp.discretization(5), table=den.sigmas, x=x, img=img)
+
+
 CASES = dict(alphas_doc=g_alphas_doc, param_contract=g_param_contract, groupnorm=g_groupnorm, timestep_embedding=g_timestep_embedding, resblock=g_resblock, updown=g_updown,
              attention=g_attention, transformer=g_transformer, unet_tiny=g_unet_tiny, unet_small_sd=g_unet_small_sd,
              vae_blocks=g_vae_blocks, vae_tiny=g_vae_tiny, schedules=g_schedules, trajectories=g_trajectories)
-FULL = dict(unet_sd15_full=g_unet_sd15_full, vae_sd15_full=g_vae_sd15_full)
+CASES.update(sgm_unet_tiny=g_sgm_unet_tiny, sgm_unet_small=g_sgm_unet_small, sgm_trajectory=g_sgm_trajectory)
+FULL = dict(unet_sd15_full=g_unet_sd15_full, vae_sd15_full=g_vae_sd15_full, sgm_unet_full=g_sgm_unet_full)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

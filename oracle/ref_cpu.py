@@ -547,3 +547,153 @@ def ddim_decode(eps_fn, x_latent, cond, uncond, cfg_scale: float, t_start: int, 
         pred_x0 = (x - (1 - a[index]).sqrt() * e) / a[index].sqrt()
         x = a_prev[index].sqrt() * pred_x0 + (1 - a_prev[index]).sqrt() * e
     return x
+
+
+# ----------------------------------------------------------------------------
+# SDXL (sgm) twins: modules/sdxl/sgm/modules/{attention.py, diffusionmodules/openaimodel.py, denoiser*.py,
+# discretizer.py, guiders.py, sampling.py}
+# ----------------------------------------------------------------------------
+def sgm_unet_layout(cfg: dict):
+    """sgm UNetModel.__init__ openaimodel.py:629-826: per-level transformer depth, heads = ch // num_head_channels
+    (:654-659), no attention where ds is not in attention_resolutions (SDXL: none at level 0)."""
+    mc = cfg["model_channels"]
+    mult = list(cfg["channel_mult"])
+    nrb = cfg["num_res_blocks"]
+    nrb = [nrb] * len(mult) if isinstance(nrb, int) else list(nrb)
+    att = set(cfg["attention_resolutions"])
+    depth = cfg.get("transformer_depth", 1)
+    depth = [depth] * len(mult) if isinstance(depth, int) else list(depth)
+    nhc = cfg.get("num_head_channels", -1)
+    nh = cfg.get("num_heads", -1)
+    heads_of = lambda ch: (ch // nhc) if nhc != -1 else nh
+    inp = [[("conv_in", None, 0)]]
+    ch, ds = mc, 1
+    for level in range(len(mult)):
+        for _ in range(nrb[level]):
+            ch = mult[level] * mc
+            layers = [("res", None, 0)]
+            if ds in att:
+                layers.append(("st", heads_of(ch), depth[level]))
+            inp.append(layers)
+        if level != len(mult) - 1:
+            inp.append([("down", None, 0)])
+            ds *= 2
+    mid = [("res", None, 0), ("st", heads_of(ch), depth[-1]), ("res", None, 0)]
+    out = []
+    for level in reversed(range(len(mult))):
+        for i in range(nrb[level] + 1):
+            ch = mc * mult[level]
+            layers = [("res", None, 0)]
+            if ds in att:
+                layers.append(("st", heads_of(ch), depth[level]))
+            if level and i == nrb[level]:
+                layers.append(("up", None, 0))
+                ds //= 2
+            out.append(layers)
+    return inp, mid, out
+
+
+def sgm_spatial_transformer(x, context, sd: SD, p: str, heads: int, depth: int, use_linear: bool):
+    """sgm SpatialTransformer.forward attention.py:1068-1133: with use_linear the 1x1 convs become nn.Linear applied
+    after / before the rearrange - the same per-pixel affine map, so only the weight's shape differs."""
+    b, c, hh, ww = x.shape
+    x_in = x
+    xn = group_norm(x, sd[p + ".norm.weight"].to(x.dtype), sd[p + ".norm.bias"].to(x.dtype), 32, 1e-6)
+    y = xn.reshape(b, c, hh * ww).permute(0, 2, 1)
+    w_in = sd[p + ".proj_in.weight"].to(x.dtype).reshape(-1, c)
+    y = F.linear(y, w_in, sd[p + ".proj_in.bias"].to(x.dtype))
+    for d in range(depth):
+        y = basic_transformer_block(y, context, sd, f"{p}.transformer_blocks.{d}", heads)
+    w_out = sd[p + ".proj_out.weight"].to(x.dtype)
+    w_out = w_out.reshape(w_out.shape[0], -1)
+    y = F.linear(y, w_out, sd[p + ".proj_out.bias"].to(x.dtype))
+    return y.permute(0, 2, 1).reshape(b, -1, hh, ww) + x_in
+
+
+def sgm_unet_forward(sd: SD, cfg: dict, x, timesteps, context, y=None):
+    """sgm UNetModel.forward openaimodel.py:828-874: emb = time_embed(timestep_embedding(t)) + label_emb(y)
+    (label_emb = Sequential(Sequential(Linear, SiLU, Linear)), :617-625,853-859); then the SD1.5 block walk."""
+    inp, mid, out = sgm_unet_layout(cfg)
+    use_linear = cfg.get("use_linear_in_transformer", False)
+    t_emb = timestep_embedding(timesteps, cfg["model_channels"]).to(x.dtype)
+    emb = linear(silu(linear(t_emb, sd, "time_embed.0")), sd, "time_embed.2")
+    if cfg.get("num_classes") is not None:
+        emb = emb + linear(silu(linear(y.to(x.dtype), sd, "label_emb.0.0")), sd, "label_emb.0.2")
+
+    def run(h, p, layers):
+        for j, (kind, heads, depth) in enumerate(layers):
+            q = f"{p}.{j}"
+            if kind == "conv_in":
+                h = conv2d(h, sd, q, padding=1)
+            elif kind == "res":
+                h = res_block(h, emb, sd, q)
+            elif kind == "st":
+                h = sgm_spatial_transformer(h, context, sd, q, heads, depth, use_linear)
+            elif kind == "down":
+                h = downsample(h, sd, q)
+            elif kind == "up":
+                h = upsample(h, sd, q)
+        return h
+
+    hs = []
+    h = x
+    for i, layers in enumerate(inp):
+        h = run(h, f"input_blocks.{i}", layers)
+        hs.append(h)
+    h = run(h, "middle_block", mid)
+    for i, layers in enumerate(out):
+        h = torch.cat([h, hs.pop()], dim=1)
+        h = run(h, f"output_blocks.{i}", layers)
+    h = group_norm(h, sd["out.0.weight"].to(h.dtype), sd["out.0.bias"].to(h.dtype), 32, 1e-5)
+    return conv2d(silu(h), sd, "out.2", padding=1)
+
+
+def legacy_ddpm_sigmas(n: int, num_timesteps: int = 1000, linear_start: float = 0.00085, linear_end: float = 0.012):
+    """LegacyDDPMDiscretization.get_sigmas discretizer.py:51-78 (+ Discretization.__call__ :20-24 appending a zero):
+    timesteps = linspace(T-1, 0, n, endpoint=False).astype(int)[::-1]; sigma = sqrt((1-a)/a) flipped to descending."""
+    import numpy as np
+    betas = make_beta_schedule_linear(num_timesteps, linear_start, linear_end).numpy()
+    acp = np.cumprod(1.0 - betas, axis=0)
+    if n < num_timesteps:
+        ts = np.linspace(num_timesteps - 1, 0, n, endpoint=False).astype(int)[::-1]
+        acp = acp[ts]
+    sig = torch.tensor((1 - acp) / acp, dtype=torch.float32) ** 0.5
+    return torch.cat([torch.flip(sig, (0,)), torch.zeros(1)])
+
+
+def discrete_denoiser_table(num_idx: int = 1000):
+    """DiscreteDenoiser.__init__ denoiser.py:42-59: sigmas = discretization(num_idx, do_append_zero=False, flip=True)
+    -> the 1000 DDPM sigmas in ASCENDING order."""
+    s = legacy_ddpm_sigmas(num_idx)[:-1]
+    return torch.flip(s, (0,))
+
+
+def sdxl_denoise(net_fn, table, x, sigma, cond: dict, uc: dict, cfg_scale: float):
+    """EDMSampler.denoise sampling.py:97-122 = VanillaCFG.prepare_inputs guiders.py:38-65 (cat uc|c for crossattn and
+    vector, x and sigma doubled) -> DiscreteDenoiser.forward denoiser.py:23-39,61-75 (sigma quantised to the nearest
+    table entry; EpsScaling denoiser_scaling.py:29-37: c_skip 1, c_out -sigma, c_in 1/sqrt(sigma^2+1), c_noise = sigma
+    -> its table INDEX) -> network(x*c_in, idx, cond) * c_out + x -> VanillaCFG.__call__ guiders.py:28-36."""
+    x2 = torch.cat([x] * 2)
+    s2 = torch.cat([sigma] * 2)
+    c = {k: torch.cat((uc[k], cond[k]), 0) for k in cond}
+    idx = (s2 - table[:, None]).abs().argmin(dim=0)
+    sq = table[idx]
+    c_in = 1 / (sq ** 2 + 1.0) ** 0.5
+    c_noise = (sq - table[:, None]).abs().argmin(dim=0)
+    out = net_fn(x2 * c_in[:, None, None, None], c_noise, c["crossattn"], c["vector"]) * (-sq)[:, None, None, None] + x2
+    x_u, x_c = out.chunk(2)
+    return x_u + cfg_scale * (x_c - x_u)
+
+
+def sdxl_sample_euler_edm(net_fn, x, cond, uc, num_steps: int, cfg_scale: float):
+    """EulerEDMSampler (sampling.py:147-219,309-318) with s_churn = 0: x *= sqrt(1 + sigma_0^2) (:83); per step
+    d = (x - denoised)/sigma, x += d * (sigma_next - sigma)."""
+    sigmas = legacy_ddpm_sigmas(num_steps)
+    table = discrete_denoiser_table()
+    x = x * torch.sqrt(1.0 + sigmas[0] ** 2.0)
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        den = sdxl_denoise(net_fn, table, x, s_in * sigmas[i], cond, uc, cfg_scale)
+        d = (x - den) / sigmas[i]
+        x = x + d * (sigmas[i + 1] - sigmas[i])
+    return x

@@ -273,3 +273,64 @@ def test_trajectory_ddim_img2img():
     close(x, g["x"], 2e-3, "ddim latent")
     ref_img = ((g["img"] + 1) / 2).clamp(0, 1)
     assert (images.cpu() - ref_img).abs().max().item() < 2e-3
+
+
+# ------------------------------------------------------------------------------------------ SDXL (sgm) twins
+@pytest.mark.parametrize("dtype", [torch.float32, BF])
+@pytest.mark.parametrize("name", ["sgm_unet_tiny", "sgm_unet_small_sdxl"])
+def test_sgm_unet_small(dtype, name):
+    """sgm UNetModel (label_emb, per-level transformer depth up to 10, linear proj_in/out, 64-wide heads) against the
+    output of the reference's sgm UNetModel"""
+    from cremage_amd.sgm_hip.unet import UNetModel
+    meta, g = load_golden(name)
+    cfg = meta["cfg"]
+    m = prep(UNetModel(**cfg), meta, dtype)
+    x = synth_input(name + ".x", (meta["B"], 4, meta["L"], meta["L"]), meta["seed"]).to(DEV)
+    ctx = synth_input(name + ".ctx", (meta["B"], meta["m"], cfg["context_dim"]), meta["seed"]).to(DEV)
+    y = synth_input(name + ".y", (meta["B"], cfg["adm_in_channels"]), meta["seed"]).to(DEV)
+    with torch.no_grad():
+        out = m(x, timesteps=g["t"].to(DEV), context=ctx, y=y)
+    close(out, g["y"], TOL_NET[dtype] * (2 if dtype == BF else 1), name)
+
+
+def test_sdxl_trajectory_euler_edm():
+    """5 EulerEDMSampler steps (DiscreteDenoiser + EpsScaling + VanillaCFG) + VAE decode vs the reference's own stack"""
+    from cremage_amd.ldm_hip.vae import AutoencoderKL
+    from cremage_amd.sgm_hip.sampling import DiffusionEngine
+    from cremage_amd.sgm_hip.unet import UNetModel
+    meta, g = load_golden("traj_sdxl_euler_edm")
+    unet = synth_fill_(UNetModel(**meta["unet"]), meta["seed"], prefix="sgm_unet.")
+    vae = synth_fill_(AutoencoderKL(meta["dd"], None, 4), meta["seed"], prefix="vae.")
+    eng = DiffusionEngine(unet, vae, meta["scale_factor"]).to(DEV).eval()
+    B, L, seed = meta["B"], meta["L"], meta["seed"]
+    c = {"crossattn": synth_input("sgmtraj.c", (B, 77, 128), seed).to(DEV), "vector": synth_input("sgmtraj.cv", (B, 96), seed).to(DEV)}
+    uc = {"crossattn": synth_input("sgmtraj.uc", (B, 77, 128), seed).to(DEV), "vector": synth_input("sgmtraj.ucv", (B, 96), seed).to(DEV)}
+    x0 = synth_input("sgmtraj.x0", (B, 4, L, L), seed).to(DEV)
+    x = eng.sample(x0, c, uc, meta["S"], meta["cfg"])
+    close(x, g["x"], 2e-3, "sdxl traj latent")
+    img = eng.decode_first_stage(x)
+    assert (img.cpu() - g["img"]).abs().max().item() < 4e-3
+
+
+@pytest.mark.parametrize("dtype", [BF])
+def test_sgm_unet_sdxl_full(dtype):
+    """Full-size SDXL UNet (2 567.46 M parameters), B=2, 128x128 latent (1024^2 image) vs the reference's sgm UNetModel"""
+    import os
+    from cremage_amd.sgm_hip.unet import UNetModel
+    from tests.conftest import GOLD
+    if not os.path.exists(os.path.join(GOLD, "sgm_unet_sdxl_full.npz")):
+        pytest.skip("full-size SDXL fixture not generated")
+    meta, g = load_golden("sgm_unet_sdxl_full")
+    cfg = meta["cfg"]
+    m = UNetModel(**cfg)
+    assert sum(p.numel() for p in m.parameters()) == meta["n_params"] == 2567463684
+    m = prep(m, meta, dtype)
+    name = "sgm_unet_sdxl_full"
+    x = synth_input(name + ".x", (2, 4, 128, 128), meta["seed"]).to(DEV)
+    ctx = synth_input(name + ".ctx", (2, 77, 2048), meta["seed"]).to(DEV)
+    y = synth_input(name + ".y", (2, 2816), meta["seed"]).to(DEV)
+    with torch.no_grad():
+        out = m(x, timesteps=g["t"].to(DEV), context=ctx, y=y)
+    r = close(out, g["y"], 8e-2, name)
+    print(f"\n[parity] SDXL UNet full {dtype}: rel-L2 {r:.3e}, max-abs {(out.cpu() - g['y']).abs().max().item():.3e} "
+          f"(|ref| max {g['y'].abs().max().item():.3f})")

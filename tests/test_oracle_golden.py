@@ -208,3 +208,39 @@ def test_trajectory_ddim_img2img():
     x = R.ddim_decode(eps, z_enc, c, uc, meta["cfg"], meta["t_enc"], ts, a, a_prev)
     assert max_abs(x, g["x"]) < 1e-3
     assert max_abs(R.decode_first_stage(vsd, meta["dd"], x), g["img"]) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------ SDXL (sgm) twins
+@pytest.mark.parametrize("name", ["sgm_unet_tiny", "sgm_unet_small_sdxl"])
+def test_sgm_unet_small(name):
+    import hashlib
+    meta, g = load_golden(name)
+    from cremage_amd.sgm_hip.unet import UNetModel
+    cfg = meta["cfg"]
+    m = UNetModel(**cfg)
+    items = sorted(f"{k}:{tuple(v.shape)}" for k, v in m.state_dict().items())
+    assert (hashlib.sha1("\n".join(items).encode()).hexdigest(), len(items)) == (meta["keys_sha1"], meta["n_keys"])
+    sd = _sd(m, meta)
+    x = synth_input(name + ".x", (meta["B"], 4, meta["L"], meta["L"]), meta["seed"])
+    ctx = synth_input(name + ".ctx", (meta["B"], meta["m"], cfg["context_dim"]), meta["seed"])
+    y = synth_input(name + ".y", (meta["B"], cfg["adm_in_channels"]), meta["seed"])
+    out = R.sgm_unet_forward(sd, cfg, x, g["t"], ctx, y)
+    assert max_abs(out, g["y"]) < 3e-4
+
+
+def test_sdxl_schedule_and_trajectory():
+    meta, g = load_golden("traj_sdxl_euler_edm")
+    from cremage_amd.ldm_hip.vae import AutoencoderKL
+    from cremage_amd.sgm_hip.unet import UNetModel
+    assert max_abs(R.legacy_ddpm_sigmas(meta["S"]), g["sigmas"]) < 1e-6
+    assert max_abs(R.discrete_denoiser_table(), g["table"]) == 0.0
+    usd = synth_state_dict(UNetModel(**meta["unet"]), meta["seed"], "sgm_unet.")
+    vsd = synth_state_dict(AutoencoderKL(meta["dd"], None, 4), meta["seed"], "vae.")
+    B, L, seed = meta["B"], meta["L"], meta["seed"]
+    c = {"crossattn": synth_input("sgmtraj.c", (B, 77, 128), seed), "vector": synth_input("sgmtraj.cv", (B, 96), seed)}
+    uc = {"crossattn": synth_input("sgmtraj.uc", (B, 77, 128), seed), "vector": synth_input("sgmtraj.ucv", (B, 96), seed)}
+    x0 = synth_input("sgmtraj.x0", (B, 4, L, L), seed)
+    net = lambda x, t, ctx, yv: R.sgm_unet_forward(usd, meta["unet"], x, t.float(), ctx, yv)
+    x = R.sdxl_sample_euler_edm(net, x0, c, uc, meta["S"], meta["cfg"])
+    assert max_abs(x, g["x"]) < 2e-3
+    assert max_abs(R.decode_first_stage(vsd, meta["dd"], x, meta["scale_factor"]), g["img"]) < 2e-3
