@@ -129,7 +129,16 @@ __global__ void pack_kernel(const ST* __restrict__ src, bf16* __restrict__ hi, b
     const int k = (int)(d - (long)o * kk);
     long s;
     if (kind == CRG_PACK_CONV) {
-      const int tap = k / n_in, ci = k - tap * n_in;
+      int tap, ci;
+      if (ks == 3 && n_in % 64 == 0) {  // chunk-major K: [Cin/64][tap][64] (see GemmP::cm in gemm_conv.hip)
+        const int taps = ks * ks;
+        const int chunk = k / (taps * 64), r = k - chunk * taps * 64;
+        tap = r / 64;
+        ci = chunk * 64 + (r - tap * 64);
+      } else {
+        tap = k / n_in;
+        ci = k - tap * n_in;
+      }
       s = ((long)o * n_in + ci) * (ks * ks) + tap;
     } else if (kind == CRG_PACK_GEGLU) {
       // packed row o: group q = o/32, r = o%32 -> source row j + half*F, j = q*16 + r%16, half = r/16

@@ -34,6 +34,8 @@ struct GemmP {
   int a_is_weight;
   // conv geometry
   const void* x2; int C1, C2, Ctot, H, W, Ho, Wo, ks, stride, pad_t, pad_l, up;
+  int cm;  // conv K order: 0 = tap-major [tap][Cin]; 1 = chunk-major [Cin/64][tap][64] (consecutive k-tiles re-read the
+           // same 64-channel slab of neighbouring pixels -> the 9 taps hit in L1 instead of going back to L2)
   int tiles_n, tiles_m;
 };
 
@@ -243,8 +245,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     const int kc = kt * BK + cc * 8;
     const bool kok = kc < p.K;
     if (CONV) {
-      const int tap = kc / p.Ctot;
-      const int c = kc - tap * p.Ctot;
+      int tap, c;
+      if (p.cm) {
+        const int taps = p.ks * p.ks;
+        tap = kt % taps;
+        c = (kt / taps) * BK + cc * 8;
+      } else {
+        tap = kc / p.Ctot;
+        c = kc - tap * p.Ctot;
+      }
       const int kh = tap / p.ks;
       const int kw = tap - kh * p.ks;
       const int Hv = p.up ? 2 * p.H : p.H, Wv = p.up ? 2 * p.W : p.W;
@@ -450,9 +459,15 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
   // running (tap, channel) of this lane's logical chunk; advanced by 64 channels per k-tile
   int kc = kt_begin * BK + clog * 8;
   int tap = 0, cch = kc;
+  const int taps = p.ks * p.ks;
   if (CONV) {
-    tap = kc / p.Ctot;
-    cch = kc - tap * p.Ctot;
+    if (p.cm) {
+      tap = kt_begin % taps;
+      cch = (kt_begin / taps) * BK + clog * 8;
+    } else {
+      tap = kc / p.Ctot;
+      cch = kc - tap * p.Ctot;
+    }
   }
   const int Hv = p.up ? 2 * p.H : p.H, Wv = p.up ? 2 * p.W : p.W;
 
@@ -490,10 +505,17 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
     // advance to the next k-tile
     kc += BK;
     if (CONV) {
-      cch += BK;
-      while (cch >= p.Ctot) {
-        cch -= p.Ctot;
-        ++tap;
+      if (p.cm) {
+        if (++tap == taps) {
+          tap = 0;
+          cch += BK;
+        }
+      } else {
+        cch += BK;
+        while (cch >= p.Ctot) {
+          cch -= p.Ctot;
+          ++tap;
+        }
       }
     }
   };
@@ -606,28 +628,31 @@ inline int choose_splits(const GemmP& p, int tiles, int batch) {
 template <int WNT, int NSPLIT, typename AT, typename YT, bool CONV>
 int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch) {
   constexpr int BN = 32 * WNT;
-  p.tiles_n = (p.N + BN - 1) / BN;
-  p.tiles_m = (p.M + BM - 1) / BM;
-  const size_t lds = 2 * NSPLIT * (BM + BN) * 128;
   constexpr bool GLDS = (NSPLIT == 1) && (sizeof(AT) == 2);
-  void (*kern)(GemmP);
-  if constexpr (GLDS) kern = gemm_glds_kernel<WNT, YT, CONV>;
-  else kern = gemm_kernel<WNT, NSPLIT, AT, YT, CONV>;
   p.zero_page = (const bf16*)ctx->zero_page;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", lds, hipGetErrorString(e));
-    attr_set = true;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const int nk = (p.K + BK - 1) / BK;
+  {
+    p.tiles_m = (p.M + BM - 1) / BM;
+    const size_t lds = 2 * NSPLIT * (BM + BN) * 128;
+    void (*kern)(GemmP);
+    if constexpr (GLDS) kern = gemm_glds_kernel<WNT, YT, CONV>;
+    else kern = gemm_kernel<WNT, NSPLIT, AT, YT, CONV>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", lds, hipGetErrorString(e));
+      attr_set = true;
+    }
+    p.splits = choose_splits(p, p.tiles_n * p.tiles_m, batch);
+    if (p.splits > 1) {
+      p.slab = (float*)crg_scratch(ctx, (size_t)batch * p.splits * p.M * p.N * sizeof(float));
+      if (!p.slab) return crg_fail(ctx, -12, "gemm: out of scratch for %d split-K slabs", p.splits);
+    }
+    dim3 grid(p.tiles_n * p.tiles_m, batch, p.splits);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    CRG_CHECK_LAUNCH(ctx, "gemm");
   }
-  p.splits = choose_splits(p, p.tiles_n * p.tiles_m, batch);
-  if (p.splits > 1) {
-    p.slab = (float*)crg_scratch(ctx, (size_t)batch * p.splits * p.M * p.N * sizeof(float));
-    if (!p.slab) return crg_fail(ctx, -12, "gemm: out of scratch for %d split-K slabs", p.splits);
-  }
-  dim3 grid(p.tiles_n * p.tiles_m, batch, p.splits);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
-  CRG_CHECK_LAUNCH(ctx, "gemm");
   if (p.splits > 1) {
     const long total = (long)p.M * (p.N >> 2);
     const int rg = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
@@ -716,6 +741,7 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
   p.cvec = a->cvec; p.cvec_rows = a->Ho * a->Wo; p.cvec_ld = a->cvec_ld ? a->cvec_ld : a->Cout;
   p.H = a->H; p.W = a->W; p.Ho = a->Ho; p.Wo = a->Wo; p.ks = a->ksize; p.stride = a->stride;
   p.pad_t = a->pad_t; p.pad_l = a->pad_l; p.up = a->upsample2x;
+  p.cm = (a->ksize == 3 && Ctot % 64 == 0) ? 1 : 0;  // must match crg_pack_weight's layout rule
   const double flops = 2.0 * p.M * (double)p.N * p.K;
   const double bytes = (double)a->N * a->H * a->W * Ctot * crg_dtype_size(a->x_dtype) + (double)p.N * p.K * 2 +
                        (double)p.M * p.N * crg_dtype_size(a->y_dtype) * (a->residual ? 2 : 1);

@@ -141,7 +141,9 @@ int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* args);
 /* ---- weight packing -------------------------------------------------------------------------
  * src: a torch parameter as the checkpoint stores it (fp32/bf16/fp16):
  *   CRG_PACK_LINEAR   [N][K]            -> [N][K]             (nn.Linear / 1x1 conv)
- *   CRG_PACK_CONV     [Cout][Cin][k][k] -> [Cout][k*k*Cin]    (tap-major, channel-minor)
+ *   CRG_PACK_CONV     [Cout][Cin][k][k] -> [Cout][k*k*Cin]    K order = [tap][Cin], or, for 3x3 with Cin % 64 == 0,
+ *                                                             [Cin/64][tap][64] (chunk-major: the 9 taps of one
+ *                                                             64-channel slab are consecutive k-tiles -> L1 reuse)
  *   CRG_PACK_GEGLU    [2*F][K]          -> rows interleaved in 16-row groups [v0-15|g0-15|v16-31|..]
  * dst_hi (and dst_lo when non-NULL: the bf16 residual src - hi) are bf16, caller-allocated. */
 enum crg_pack_kind { CRG_PACK_LINEAR = 0, CRG_PACK_CONV = 1, CRG_PACK_GEGLU = 2 };

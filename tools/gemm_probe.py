@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""Dev probe: time one conv / GEMM shape (events over many reps, host queue kept full) - used with CRG_GEMM8=0/1 and
+under rocprofv3 --pmc to see what bounds the MFMA kernels."""
+import argparse, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cremage_amd import ops
+ap = argparse.ArgumentParser()
+ap.add_argument("--kind", default="conv")
+ap.add_argument("--reps", type=int, default=50)
+a = ap.parse_args()
+dev = "cuda:0"
+torch.manual_seed(0)
+shapes = {
+    "conv": [(8, 320, 64, 320), (8, 640, 32, 640), (8, 1280, 16, 1280), (8, 640, 64, 320)],
+    "gemm": [(32768, 320, 2880), (32768, 2560, 320), (8192, 640, 640), (8192, 5120, 640), (2048, 1280, 1280), (32768, 320, 320)],
+}[a.kind]
+for sh in shapes:
+    if a.kind == "conv":
+        n, ci, hw, co = sh
+        x = torch.randn(n, ci, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(co, ci, 3, 3, device=dev) * 0.02).to(torch.bfloat16)
+        b = torch.zeros(co, device=dev)
+        f = lambda: ops.conv2d(x, w, b)
+        fl = 2.0 * n * hw * hw * co * ci * 9
+    else:
+        m, nn, k = sh
+        x = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = (torch.randn(nn, k, device=dev) * 0.02).to(torch.bfloat16)
+        f = lambda: ops.linear(x, w)
+        fl = 2.0 * m * nn * k
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / a.reps
+    print(f"{a.kind} {sh}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF   (CRG_GEMM8={os.environ.get('CRG_GEMM8')})", flush=True)
