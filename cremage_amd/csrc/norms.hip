@@ -70,41 +70,28 @@ __global__ __launch_bounds__(512) void gn_stats_kernel(const T* __restrict__ x, 
         a2[e] += d * d;
       }
     }
-    // combine this lane's 8 channels by group in registers first (<= 2 groups when C/groups >= 8), so that
-    // the LDS atomics are 2-4 per lane instead of 16 on a handful of hot addresses
-    if (gid[0] == gid[7]) {
-      float b1 = 0.f, b2 = 0.f;
+  }
+  // Deterministic block reduction (no float atomics: results must not depend on arrival order): every lane parks its
+  // 8 per-channel partials in LDS, then one lane per group adds its group's channels x row-lanes in a fixed order.
+  __shared__ float red[512 * 16];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        b1 += a1[e];
-        b2 += a2[e];
-      }
-      atomicAdd(&s1[gid[0]], b1);
-      atomicAdd(&s2[gid[0]], b2);
-    } else if (gs >= 8) {
-      float b1 = 0.f, b2 = 0.f, c1 = 0.f, c2 = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const bool first = gid[e] == gid[0];
-        b1 += first ? a1[e] : 0.f;
-        b2 += first ? a2[e] : 0.f;
-        c1 += first ? 0.f : a1[e];
-        c2 += first ? 0.f : a2[e];
-      }
-      atomicAdd(&s1[gid[0]], b1);
-      atomicAdd(&s2[gid[0]], b2);
-      atomicAdd(&s1[gid[7]], c1);
-      atomicAdd(&s2[gid[7]], c2);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        atomicAdd(&s1[gid[e]], a1[e]);
-        atomicAdd(&s2[gid[e]], a2[e]);
-      }
-    }
+  for (int e = 0; e < 8; ++e) {
+    red[t * 16 + e] = (rl < rpi) ? a1[e] : 0.f;
+    red[t * 16 + 8 + e] = (rl < rpi) ? a2[e] : 0.f;
   }
   __syncthreads();
   if (t < groups) {
+    float b1 = 0.f, b2 = 0.f;
+    for (int c = t * gs; c < (t + 1) * gs; ++c) {
+      const int cl = c >> 3, e = c & 7;
+      for (int r2 = 0; r2 < rpi; ++r2) {
+        const float* q = red + (r2 * tpr + cl) * 16;
+        b1 += q[e];
+        b2 += q[8 + e];
+      }
+    }
+    s1[t] = b1;
+    s2[t] = b2;
     float* o = part + (((long)n * gridDim.x + chunk) * groups + t) * 2;
     o[0] = s1[t];
     o[1] = s2[t];

@@ -484,6 +484,32 @@ def g_param_contract():
                                 ipa_num_tokens=4), dummy=np.zeros(1))
 
 
+def g_controlnet_hook():
+    """ControlNet's hook into the UNet: the reference's ControlledUnetModel (cldm.py:28-70, a UNetModel subclass whose
+    forward adds the control residuals after the middle block and to every skip) on the tiny UNet with synthetic
+    control tensors."""
+    from cldm.cldm import ControlledUnetModel
+    m = ControlledUnetModel(**TINY_UNET)
+    synth_fill_(m, SEED, prefix="unet.")
+    B, L = 2, 16
+    x = synth_input("cn.x", (B, 4, L, L), SEED)
+    ctx = synth_input("cn.ctx", (B, 77, TINY_UNET["context_dim"]), SEED)
+    t = torch.tensor([250.0, 600.5])
+    shapes = [(64, 16, 16), (64, 16, 16), (64, 8, 8), (128, 8, 8), (128, 8, 8)]  # 4 skips + middle (popped first)
+    control = [synth_input(f"cn.control{i}", (B,) + s, SEED, 0.3) for i, s in enumerate(shapes)]
+    # cldm.py:54-55,67-68 cast to fp16 whenever the tensor is not on a 'cuda' device (Mac path, keyed on device.type, not
+    # on is_available): neutralise Tensor.half for the duration of the forward so the path stays fp32
+    orig_half = torch.Tensor.half
+    torch.Tensor.half = lambda self, *a, **k: self
+    try:
+        with fp32_forward():
+            y = m(x, timesteps=t, context=ctx, control=[c.clone() for c in control], only_mid_control=False)
+            y_mid = m(x, timesteps=t, context=ctx, control=[c.clone() for c in control], only_mid_control=True)
+    finally:
+        torch.Tensor.half = orig_half
+    save("hook_controlnet", dict(cfg=TINY_UNET, B=B, L=L, seed=SEED, prefix="unet.", shapes=shapes), t=t, y=y, y_mid=y_mid)
+
+
 # ---------------------------------------------------------------------------- SDXL (sgm)
 
 TINY_SGM_UNET = dict(adm_in_channels=96, num_classes="sequential", use_checkpoint=False, in_channels=4, out_channels=4,
@@ -571,6 +597,7 @@ def g_sgm_trajectory():
 CASES = dict(alphas_doc=g_alphas_doc, param_contract=g_param_contract, groupnorm=g_groupnorm, timestep_embedding=g_timestep_embedding, resblock=g_resblock, updown=g_updown,
              attention=g_attention, transformer=g_transformer, unet_tiny=g_unet_tiny, unet_small_sd=g_unet_small_sd,
              vae_blocks=g_vae_blocks, vae_tiny=g_vae_tiny, schedules=g_schedules, trajectories=g_trajectories)
+CASES.update(controlnet_hook=g_controlnet_hook)
 CASES.update(sgm_unet_tiny=g_sgm_unet_tiny, sgm_unet_small=g_sgm_unet_small, sgm_trajectory=g_sgm_trajectory)
 FULL = dict(unet_sd15_full=g_unet_sd15_full, vae_sd15_full=g_vae_sd15_full, sgm_unet_full=g_sgm_unet_full)
 

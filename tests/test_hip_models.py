@@ -334,3 +334,74 @@ def test_sgm_unet_sdxl_full(dtype):
     r = close(out, g["y"], 8e-2, name)
     print(f"\n[parity] SDXL UNet full {dtype}: rel-L2 {r:.3e}, max-abs {(out.cpu() - g['y']).abs().max().item():.3e} "
           f"(|ref| max {g['y'].abs().max().item():.3f})")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, BF])
+def test_controlnet_hook_attaches(dtype):
+    """'ControlNet hooks still attach': a subclass written exactly like the reference's ControlledUnetModel
+    (cldm.py:28-70 - it walks time_embed / input_blocks / middle_block / output_blocks / out itself, adds the control
+    residuals in place and concatenates skips with th.cat) runs on the HIP module tree and matches the reference."""
+    from cremage_amd.ldm_hip.nn import timestep_embedding
+    from cremage_amd.ldm_hip.unet import UNetModel
+
+    class ControlledUnetModel(UNetModel):
+        def forward(self, x, timesteps=None, context=None, control=None, only_mid_control=False, **kwargs):
+            hs = []
+            with torch.no_grad():
+                t_emb = timestep_embedding(timesteps, self.model_channels, repeat_only=False)
+                emb = self.time_embed(t_emb)
+                h = x.type(self.dtype)
+                for module in self.input_blocks:
+                    h = module(h, emb, context)
+                    hs.append(h)
+                h = self.middle_block(h, emb, context)
+            if control is not None:
+                h += control.pop()
+            for i, module in enumerate(self.output_blocks):
+                if only_mid_control or control is None:
+                    h = torch.cat([h, hs.pop()], dim=1)
+                else:
+                    h = torch.cat([h, hs.pop() + control.pop()], dim=1)
+                h = module(h, emb, context)
+            h = h.type(x.dtype)
+            return self.out(h)
+
+    meta, g = load_golden("hook_controlnet")
+    cfg = meta["cfg"]
+    m = prep(ControlledUnetModel(**cfg), meta, dtype)
+    m.dtype = dtype  # the reference's `use_fp16` switch (openaimodel.py:532) - here: the activation dtype of the walk
+    B, L, seed = meta["B"], meta["L"], meta["seed"]
+    x = synth_input("cn.x", (B, 4, L, L), seed).to(DEV).to(dtype)
+    ctx = synth_input("cn.ctx", (B, 77, cfg["context_dim"]), seed).to(DEV).to(dtype)
+    control = [synth_input(f"cn.control{i}", (B,) + tuple(s), seed, 0.3).to(DEV).to(dtype) for i, s in enumerate(meta["shapes"])]
+    t = g["t"].to(DEV)
+    with torch.no_grad():
+        y = m(x, timesteps=t, context=ctx, control=[c.clone() for c in control])
+        y_mid = m(x, timesteps=t, context=ctx, control=[c.clone() for c in control], only_mid_control=True)
+    close(y, g["y"], TOL_NET[dtype], "controlnet hook")
+    close(y_mid, g["y_mid"], TOL_NET[dtype], "controlnet hook (mid only)")
+
+
+def test_c4_unit_img2img_768_properties():
+    """BASELINE.json configs[3]'s per-GPU unit at full size (SD1.5 img2img 768x768, 2 images, DDIM, strength 0.75 ->
+    t_enc = 15 of 20 steps, VAE encode + decode) through size-independent properties: determinism (bitwise), and
+    sample independence (an image computed in a batch of 2 == the same image computed alone) - the property the
+    batch-sharded multi-GPU mode rests on."""
+    from cremage_amd import pipeline as P
+    ldm = P.build_synthetic_ldm(device=DEV, seed=99)
+    b = 2
+    img = (synth_input("c4.img", (b, 3, 768, 768), 44, 0.5).clamp(-1, 1)).to(DEV)
+    c = synth_input("c4.c", (b, 77, 768), 7).to(DEV)
+    uc = synth_input("c4.uc", (1, 77, 768), 7).expand(b, -1, -1).contiguous().to(DEV)
+    en = synth_input("c4.en", (b, 4, 96, 96), 45).to(DEV)
+    fn = synth_input("c4.fn", (b, 4, 96, 96), 46).to(DEV)
+    run = lambda sl: P.img2img(ldm, img[sl], c[sl], uc[sl], steps=20, strength=0.75, cfg_scale=7.5, enc_noise=en[sl], fwd_noise=fn[sl])
+    im_a, z_a = run(slice(0, 2))
+    im_b, z_b = run(slice(0, 2))
+    assert im_a.shape == (2, 3, 768, 768) and z_a.shape == (2, 4, 96, 96)
+    assert torch.isfinite(im_a).all() and im_a.min() >= 0 and im_a.max() <= 1
+    assert torch.equal(im_a, im_b) and torch.equal(z_a, z_b)
+    im_1, z_1 = run(slice(1, 2))
+    # bf16 UNet: split-K / tile shapes differ with the batch, so equality is to bf16 round-off, not bitwise
+    assert rel_l2(z_1.cpu(), z_a[1:2].cpu()) < 3e-2
+    assert (im_1.cpu() - im_a[1:2].cpu()).abs().mean().item() < 2e-2

@@ -244,3 +244,17 @@ def test_sdxl_schedule_and_trajectory():
     x = R.sdxl_sample_euler_edm(net, x0, c, uc, meta["S"], meta["cfg"])
     assert max_abs(x, g["x"]) < 2e-3
     assert max_abs(R.decode_first_stage(vsd, meta["dd"], x, meta["scale_factor"]), g["img"]) < 2e-3
+
+
+def test_controlnet_hook_oracle():
+    """oracle's `control=` path (cldm.py:57-65) against the reference's ControlledUnetModel"""
+    meta, g = load_golden("hook_controlnet")
+    from cremage_amd.ldm_hip.unet import UNetModel
+    cfg = meta["cfg"]
+    sd = _sd(UNetModel(**cfg), meta)
+    B, L, seed = meta["B"], meta["L"], meta["seed"]
+    x = synth_input("cn.x", (B, 4, L, L), seed)
+    ctx = synth_input("cn.ctx", (B, 77, cfg["context_dim"]), seed)
+    control = [synth_input(f"cn.control{i}", (B,) + tuple(s), seed, 0.3) for i, s in enumerate(meta["shapes"])]
+    y = R.unet_forward(sd, cfg, x, g["t"], ctx, control=control)
+    assert max_abs(y, g["y"]) < 2e-4
