@@ -15,17 +15,15 @@ int crg_fail(crg_ctx* ctx, int code, const char* fmt, ...) {
 
 void* crg_scratch(crg_ctx* ctx, size_t bytes) {
   if (ctx->scratch_bytes >= bytes) return ctx->scratch;
-  if (ctx->scratch) {
-    (void)hipDeviceSynchronize();
-    (void)hipFree(ctx->scratch);
-    ctx->scratch = nullptr;
-    ctx->scratch_bytes = 0;
-  }
-  size_t want = bytes < (size_t(8) << 20) ? (size_t(8) << 20) : bytes;
-  if (hipMalloc(&ctx->scratch, want) != hipSuccess) {
-    ctx->scratch = nullptr;
-    return nullptr;
-  }
+  // Grow geometrically and RETIRE (do not free) the old buffer: a captured hipGraph may have its address baked into
+  // kernel arguments, and kernels already queued on the stream may still be using it.  Retired buffers are released
+  // with the context.  Growth itself is a hipMalloc, i.e. not capture-safe: reserve before capturing.
+  size_t want = ctx->scratch_bytes ? ctx->scratch_bytes * 2 : (size_t(64) << 20);
+  while (want < bytes) want *= 2;
+  void* fresh = nullptr;
+  if (hipMalloc(&fresh, want) != hipSuccess) return nullptr;
+  if (ctx->scratch) ctx->retired.push_back(ctx->scratch);
+  ctx->scratch = fresh;
   ctx->scratch_bytes = want;
   return ctx->scratch;
 }
@@ -67,6 +65,7 @@ extern "C" int crg_ctx_create(int device, crg_ctx** out) {
 extern "C" void crg_ctx_destroy(crg_ctx* ctx) {
   if (!ctx) return;
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  for (void* p : ctx->retired) (void)hipFree(p);
   if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   for (auto& r : ctx->recs) {
     (void)hipEventDestroy(r.e0);

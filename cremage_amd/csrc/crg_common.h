@@ -32,6 +32,7 @@ struct crg_ctx {
   std::string err;
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  std::vector<void*> retired;  // outgrown scratch buffers (kept alive: captured graphs / queued kernels may reference them)
   void* zero_page = nullptr;  // 4 KiB of zeros: LDS-DMA source for conv padding and tile tails
   bool profiling = false;
   std::vector<crg_prof_rec> recs;

@@ -45,8 +45,20 @@ class DiffusionWrapper(nn.Module):
         self.conditioning_key = conditioning_key
         assert conditioning_key == "crossattn", "only the SD 'crossattn' conditioning is restated"
 
+        self.graphed = None  # set by enable_hip_graph()
+
+    def enable_hip_graph(self, on: bool = True):
+        """Replay the UNet call from a captured hipGraph (cremage_amd.graphs) instead of ~390 eager launches."""
+        if on:
+            from ..graphs import GraphedModule
+            self.graphed = GraphedModule(self.diffusion_model)
+        else:
+            self.graphed = None
+
     def forward(self, x, t, c_concat: list = None, c_crossattn: list = None):
         cc = c_crossattn[0] if len(c_crossattn) == 1 else torch.cat(c_crossattn, 1)
+        if self.graphed is not None and x.is_cuda:
+            return self.graphed(x, timesteps=t, context=cc)
         return self.diffusion_model(x, t, context=cc)
 
 

@@ -132,7 +132,14 @@ class LDMWrapperForKDiffusion(nn.Module):
         self.unconditional_guidance_scale = unconditional_guidance_scale
         self._c_in = None
 
+    _cat_memo = None  # (c, uc, c_in): one concatenated conditioning per (c, uc) pair across sampler instances, so that the
+    #                   modules' K/V cache and a captured hipGraph (keyed on the tensor identity) survive from batch to batch
+
     def _cat_cond(self):
+        m = LDMWrapperForKDiffusion._cat_memo
+        if self._c_in is None and m is not None and m[0] is self.c and m[1] is self.unconditional_conditioning \
+                and torch.is_tensor(self.c) and m[3] == (self.c._version, self.unconditional_conditioning._version):
+            self._c_in = m[2]
         if self._c_in is None:
             c, uc = self.c, self.unconditional_conditioning
             if isinstance(c, dict):
@@ -145,6 +152,7 @@ class LDMWrapperForKDiffusion(nn.Module):
                         c_in[k] = torch.cat([uc[k], c[k]])
             else:
                 c_in = {"c_crossattn": [torch.cat([uc, c])]}
+                LDMWrapperForKDiffusion._cat_memo = (c, uc, c_in, (c._version, uc._version))
             self._c_in = c_in
         return self._c_in
 

@@ -405,3 +405,24 @@ def test_c4_unit_img2img_768_properties():
     # bf16 UNet: split-K / tile shapes differ with the batch, so equality is to bf16 round-off, not bitwise
     assert rel_l2(z_1.cpu(), z_a[1:2].cpu()) < 3e-2
     assert (im_1.cpu() - im_a[1:2].cpu()).abs().mean().item() < 2e-2
+
+
+def test_hip_graph_replay_equals_eager():
+    """hipGraph replay of the UNet call (cremage_amd.graphs) is bitwise the eager result, for changing x / t and after a
+    context change (re-capture), on the SD-shaped small UNet."""
+    from cremage_amd.graphs import GraphedModule
+    from cremage_amd.ldm_hip.unet import UNetModel
+    meta, g = load_golden("unet_small_sd")
+    cfg = meta["cfg"]
+    m = prep(UNetModel(**cfg), meta, BF)
+    gm = GraphedModule(m, scratch_bytes=64 << 20)
+    ctx1 = synth_input("graph.ctx1", (4, 77, cfg["context_dim"]), 3).to(DEV)
+    ctx2 = synth_input("graph.ctx2", (4, 77, cfg["context_dim"]), 4).to(DEV)
+    with torch.no_grad():
+        for step, ctx in enumerate([ctx1, ctx1, ctx1, ctx2, ctx2]):
+            x = synth_input(f"graph.x{step}", (4, 4, 16, 16), 5).to(DEV)
+            t = torch.full((4,), 900.0 - 100.5 * step, device=DEV)
+            y_graph = gm(x, timesteps=t, context=ctx)
+            y_eager = m(x, timesteps=t, context=ctx)
+            assert torch.equal(y_graph, y_eager), step
+    assert len(gm._graphs) == 2
