@@ -16,6 +16,9 @@ LIB = os.path.join(HERE, "libcrg_hip.so")
 SOURCES = ["crg_api.hip", "gemm_conv.hip", "norms.hip", "attention.hip", "small_ops.hip"]
 HEADERS = [os.path.join(CSRC, "crg_common.h"), os.path.join(HERE, "..", "include", "crg_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+# attention.hip: without NaN-honouring semantics fmaxf lowers to plain v_max_f32 / v_max3_f32 instead of a canonicalising
+# v_max per MFMA output (32 extra VALU per 64-key tile in a VALU-bound loop).  Infinities (the -inf key mask) are kept.
+EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc():
@@ -34,7 +37,7 @@ def _compile(src):
     o = os.path.join(OBJ, src.replace(".hip", ".o"))
     if not (_newer(s, o) or any(_newer(h, o) for h in HEADERS)):
         return o, False
-    cmd = [_hipcc()] + FLAGS + ["-c", s, "-o", o]
+    cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")

@@ -78,28 +78,44 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
   float m_run = -INFINITY, l_run = 0.f;  // m_run in scaled (log2) units
 
   bf16x8 kreg[KLOADS], vreg[NV];
+  // per-lane source pointers of the K / V^T chunks this lane stages (tile-invariant part), advanced by 64 keys per tile
+  const bf16* kptr[KLOADS];
+  bool kuse[KLOADS];
+#pragma unroll
+  for (int i = 0; i < KLOADS; ++i) {
+    const int idx = t + 256 * i;
+    const int row = idx / KCH, c = idx - row * KCH;
+    kuse[i] = idx < 64 * KCH && c * 8 < p.Dh;
+    kptr[i] = K + (long)row * p.ldk + c * 8;
+  }
+  const bf16* vptr[NV];
+  int vmode[NV];  // 0 = zero row, 1 = data row, 2 = all-ones row
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = t + 256 * i;
+    const int row = idx >> 3, c = idx & 7;
+    vmode[i] = row < p.Dh ? 1 : ((ones_row && row == p.Dh) ? 2 : 0);
+    vptr[i] = VT + (long)row * p.ldvt + c * 8;
+  }
   auto prefetch = [&](int tile) {
+    const int kbase = tile * 64;
 #pragma unroll
     for (int i = 0; i < KLOADS; ++i) {
-      const int idx = t + 256 * i;
-      const int row = idx / KCH, c = idx - row * KCH;
-      const int key = tile * 64 + row;
-      kreg[i] = (idx < 64 * KCH && key < p.Nk && c * 8 < p.Dh) ? *reinterpret_cast<const bf16x8*>(K + (long)key * p.ldk + c * 8) : zero8;
+      const int row = (t + 256 * i) / KCH;
+      kreg[i] = (kuse[i] && kbase + row < p.Nk) ? *reinterpret_cast<const bf16x8*>(kptr[i] + (long)kbase * p.ldk) : zero8;
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int idx = t + 256 * i;
-      const int row = idx >> 3, c = idx & 7;
-      const int key0 = tile * 64 + c * 8;
+      const int key0 = kbase + ((t + 256 * i) & 7) * 8;
       bf16x8 v = zero8;
-      if (row < p.Dh && key0 < p.Nk) {
-        v = *reinterpret_cast<const bf16x8*>(VT + (long)row * p.ldvt + key0);
+      if (vmode[i] == 1 && key0 < p.Nk) {
+        v = *reinterpret_cast<const bf16x8*>(vptr[i] + kbase);
         if (key0 + 8 > p.Nk) {
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             if (key0 + e >= p.Nk) v[e] = (bf16)0.f;
         }
-      } else if (ones_row && row == p.Dh) {
+      } else if (vmode[i] == 2) {
         v = ones8;
       }
       vreg[i] = v;
