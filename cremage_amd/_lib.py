@@ -8,15 +8,19 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrg_hip.so")
+# CRG_LIB: developer override used for A/B runs of two builds on the same GPU box (tools/); the default is the in-tree build
+LIB_PATH = os.path.abspath(os.environ["CRG_LIB"]) if os.environ.get("CRG_LIB") else os.path.join(_HERE, "libcrg_hip.so")
 
 BF16, F32, F16 = 0, 1, 2
 PREC_BF16, PREC_BF16X3 = 0, 1
 EPI_NONE, EPI_SILU, EPI_GEGLU = 0, 1, 2
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 PACK_LINEAR, PACK_CONV, PACK_GEGLU = 0, 1, 2
-K_FAMILIES = 8
-FAMILY_NAMES = ["gemm", "conv", "attention", "groupnorm", "layernorm", "elementwise", "conv_small", "softmax"]
+K_SLOTS = 16  # enum crg_kernel_slot
+SLOT_NAMES = ["gemm_w1", "gemm_w4", "gemm_w5", "gemm_x3", "conv_w1", "conv_w4", "conv_w5", "conv_x3", "splitk_reduce", "attention",
+              "gn_stats", "gn_apply", "layernorm", "elementwise", "conv_small", "softmax"]
+SLOT_FAMILY = ["gemm", "gemm", "gemm", "gemm", "conv", "conv", "conv", "conv", "splitk_reduce", "attention", "groupnorm", "groupnorm",
+               "layernorm", "elementwise", "conv_small", "softmax"]
 
 c_void_p, c_int, c_int64, c_float, c_size_t = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -53,8 +57,8 @@ class ConvArgs(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("ms", C.c_double * K_FAMILIES), ("flops", C.c_double * K_FAMILIES), ("bytes", C.c_double * K_FAMILIES),
-                ("launches", C.c_int64 * K_FAMILIES)]
+    _fields_ = [("ms", C.c_double * K_SLOTS), ("flops", C.c_double * K_SLOTS), ("bytes", C.c_double * K_SLOTS),
+                ("launches", C.c_int64 * K_SLOTS)]
 
 
 # name -> (restype, argtypes); every symbol include/crg_hip.h declares
@@ -64,6 +68,7 @@ SIGNATURES = {
     "crg_ctx_destroy": (None, [c_void_p]),
     "crg_last_error": (C.c_char_p, [c_void_p]),
     "crg_ctx_reserve": (c_int, [c_void_p, c_size_t]),
+    "crg_kernel_name": (C.c_char_p, [c_int]),
     "crg_profile_begin": (c_int, [c_void_p]),
     "crg_profile_end": (c_int, [c_void_p, c_void_p, C.POINTER(Profile)]),
     "crg_groupnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

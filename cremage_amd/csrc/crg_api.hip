@@ -81,6 +81,17 @@ extern "C" int crg_ctx_reserve(crg_ctx* ctx, size_t bytes) {
   return crg_scratch(ctx, bytes) ? 0 : crg_fail(ctx, -12, "cannot reserve %zu bytes of scratch", bytes);
 }
 
+extern "C" const char* crg_kernel_name(int slot) {
+  static const char* const names[CRG_K_SLOTS] = {
+      "gemm_glds_kernel<1, YT, false>", "gemm_glds_kernel<4, YT, false>", "gemm_glds_kernel<5, YT, false>",
+      "gemm_kernel<WNT, NSPLIT, AT, YT, false>",
+      "gemm_glds_kernel<1, YT, true>",  "gemm_glds_kernel<4, YT, true>",  "gemm_glds_kernel<5, YT, true>",
+      "gemm_kernel<WNT, NSPLIT, AT, YT, true>",
+      "splitk_reduce_kernel<YT>", "attn_kernel<KS, NV>", "gn_stats_kernel<T>", "gn_apply_kernel<T>", "layernorm_kernel<T>",
+      "elementwise (silu / axpby / affine_cast / transpose / timestep_embedding kernels)", "conv_small_*_kernel", "softmax_rows_kernel<T>"};
+  return (slot >= 0 && slot < CRG_K_SLOTS) ? names[slot] : "?";
+}
+
 extern "C" int crg_profile_begin(crg_ctx* ctx) {
   if (!ctx) return -22;
   for (auto& r : ctx->recs) {
@@ -96,13 +107,13 @@ extern "C" int crg_profile_end(crg_ctx* ctx, void* stream, crg_profile* out) {
   if (!ctx || !out) return -22;
   ctx->profiling = false;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return crg_fail(ctx, -5, "profile_end: stream sync failed");
-  for (int i = 0; i < CRG_K_FAMILIES; ++i) {
+  for (int i = 0; i < CRG_K_SLOTS; ++i) {
     out->ms[i] = out->flops[i] = out->bytes[i] = 0.0;
     out->launches[i] = 0;
   }
   for (auto& r : ctx->recs) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess && r.family >= 0 && r.family < CRG_K_FAMILIES) {
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess && r.family >= 0 && r.family < CRG_K_SLOTS) {
       out->ms[r.family] += ms;
       out->flops[r.family] += r.flops;
       out->bytes[r.family] += r.bytes;

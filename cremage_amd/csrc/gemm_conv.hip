@@ -37,10 +37,40 @@ struct GemmP {
   int cm;  // conv K order: 0 = tap-major [tap][Cin]; 1 = chunk-major [Cin/64][tap][64] (consecutive k-tiles re-read the
            // same 64-channel slab of neighbouring pixels -> the 9 taps hit in L1 instead of going back to L2)
   int tiles_n, tiles_m;
+  int xg_m, xg_n, xg_s;  // XCD partition of the (m-tile, n-tile, k-slice) grid, product 8; xg_s == 0: legacy contiguous order
 };
 
 constexpr int BM = 128;
 constexpr int BK = 64;
+
+// Block -> (m-tile, n-tile, k-slice).  The dispatcher deals workgroups round-robin to the 8 XCDs (block L runs on XCD
+// L % 8) and every XCD has its own 4 MB L2, so whatever two XCDs both touch is fetched twice over the fabric.  The host
+// picks a partition (xg_m x xg_n x xg_s = 8) of the tile grid that minimises xg_n * |A| + xg_m * |W| (k-slices share
+// nothing, so cutting along split-K is free): activation-heavy shapes (64x64 levels) give every XCD a contiguous run of
+// m-tiles and the whole small W, weight-heavy shapes (8x8 / 16x16 levels, 1280-wide) give every XCD its own slice of W.
+// Inside an XCD the order is n fastest, then m, then k-slice, so co-resident blocks share A rows and W panels.
+__device__ __forceinline__ void block_to_tile(const GemmP& p, int& tile_m, int& tile_n, int& sid) {
+  const int L = blockIdx.x;
+  if (p.xg_s) {
+    const int xcd = L & 7, idx = L >> 3;
+    const int xs = xcd % p.xg_s, xr = xcd / p.xg_s;
+    const int xn = xr % p.xg_n, xm = xr / p.xg_n;
+    const int nnl = p.tiles_n / p.xg_n, nml = p.tiles_m / p.xg_m, nsl = p.splits / p.xg_s;
+    const int tn = idx % nnl, r = idx / nnl;
+    const int tm = r % nml, ts = r / nml;
+    tile_n = xn * nnl + tn;
+    tile_m = xm * nml + tm;
+    sid = xs * nsl + ts;
+  } else {  // tile counts not divisible: contiguous runs of tiles per XCD (bijective for any count)
+    const int T = p.tiles_n * p.tiles_m;
+    sid = L / T;
+    int bid = L - sid * T;
+    const int q = T >> 3, r = T & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    tile_n = bid % p.tiles_n;
+    tile_m = bid / p.tiles_n;
+  }
+}
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
@@ -183,17 +213,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   const int wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // XCD-aware tile order: blocks b, b+8, ... share an XCD (L2); give each XCD a contiguous run of
-  // tiles ordered n-fastest so neighbouring blocks reuse the same activation rows and the whole
-  // weight panel stays L2-resident (guide T1, bijective form).
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tile_n = bid % p.tiles_n;
-  const int tile_m = bid / p.tiles_n;
+  int tile_m, tile_n, sid;
+  block_to_tile(p, tile_m, tile_n, sid);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int bz = blockIdx.y;
 
@@ -330,7 +351,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk_total = (p.K + BK - 1) / BK;
-  const int sid = blockIdx.z;
   const int kt_begin = (int)((long)nk_total * sid / p.splits);
   const int nk = (int)((long)nk_total * (sid + 1) / p.splits);
   load_tile(kt_begin);
@@ -401,14 +421,8 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tile_n = bid % p.tiles_n;
-  const int tile_m = bid / p.tiles_n;
+  int tile_m, tile_n, sid;
+  block_to_tile(p, tile_m, tile_n, sid);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int bz = blockIdx.y;
 
@@ -452,7 +466,6 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
   }
 
   const int nk_total = (p.K + BK - 1) / BK;
-  const int sid = blockIdx.z;
   const int kt_begin = (int)((long)nk_total * sid / p.splits);
   const int nk = (int)((long)nk_total * (sid + 1) / p.splits);
 
@@ -618,15 +631,41 @@ inline int choose_splits(const GemmP& p, int tiles, int batch) {
   if (p.epi == CRG_EPI_GEGLU || (p.N & 3)) return 1;
   const int nk = (p.K + BK - 1) / BK;
   const long blocks = (long)tiles * batch;
-  if (blocks >= 256 || nk < 24) return 1;
+  // 256..511 blocks leave one block (4 waves) on most CUs, which hides neither the barrier nor the DMA latency: cut K in
+  // two when it is long enough to amortise the slab pass (measured: 8x32x32 640->640 conv 112 -> 89 us, 1280->640 203 -> 137 us;
+  // K = 2560 GEMMs lose 5 %, hence the nk bound)
+  if (blocks >= 512 || nk < 24 || (blocks >= 256 && nk < 64)) return 1;
   int s = (int)((512 + blocks - 1) / blocks);
   if (s > nk / 8) s = nk / 8;
   if (s > 16) s = 16;
   return s < 2 ? 1 : s;
 }
 
+struct Work {  // algorithmic work of one call (profiler) and operand footprints (XCD partition)
+  double flops, bytes, a_bytes, w_bytes;
+};
+
+// (xg_m, xg_n, xg_s): see block_to_tile.  Minimise fabric traffic xg_n*|A| + xg_m*|W| over the feasible factorizations of 8.
+inline void choose_xcd_partition(GemmP& p, const Work& wk) {
+  p.xg_m = p.xg_n = 1;
+  p.xg_s = 0;
+  double best = 0.0;
+  for (int gs = 8; gs >= 1; gs >>= 1) {
+    if (p.splits % gs) continue;
+    for (int gn = 1; gn * gs <= 8; gn <<= 1) {
+      const int gm = 8 / (gs * gn);
+      if (p.tiles_n % gn || p.tiles_m % gm) continue;
+      const double cost = gn * wk.a_bytes + gm * wk.w_bytes;
+      if (!p.xg_s || cost < best) {
+        best = cost;
+        p.xg_m = gm; p.xg_n = gn; p.xg_s = gs;
+      }
+    }
+  }
+}
+
 template <int WNT, int NSPLIT, typename AT, typename YT, bool CONV>
-int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch) {
+int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   constexpr int BN = 32 * WNT;
   constexpr bool GLDS = (NSPLIT == 1) && (sizeof(AT) == 2);
   p.zero_page = (const bf16*)ctx->zero_page;
@@ -649,13 +688,20 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch) {
       p.slab = (float*)crg_scratch(ctx, (size_t)batch * p.splits * p.M * p.N * sizeof(float));
       if (!p.slab) return crg_fail(ctx, -12, "gemm: out of scratch for %d split-K slabs", p.splits);
     }
-    dim3 grid(p.tiles_n * p.tiles_m, batch, p.splits);
+    choose_xcd_partition(p, wk);
+    dim3 grid(p.tiles_n * p.tiles_m * p.splits, batch, 1);
+    constexpr int slot = !GLDS ? (CONV ? CRG_K_CONV_X3 : CRG_K_GEMM_X3)
+                               : (CONV ? (WNT == 5 ? CRG_K_CONV_W5 : WNT == 4 ? CRG_K_CONV_W4 : CRG_K_CONV_W1)
+                                       : (WNT == 5 ? CRG_K_GEMM_W5 : WNT == 4 ? CRG_K_GEMM_W4 : CRG_K_GEMM_W1));
+    crg_prof_scope ps(ctx, st, slot, wk.flops, wk.bytes);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
     CRG_CHECK_LAUNCH(ctx, "gemm");
   }
   if (p.splits > 1) {
     const long total = (long)p.M * (p.N >> 2);
     const int rg = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    crg_prof_scope ps(ctx, st, CRG_K_SPLITK, (double)batch * p.splits * p.M * p.N,
+                      (double)batch * p.M * p.N * (4.0 * p.splits + sizeof(YT)));
     hipLaunchKernelGGL(splitk_reduce_kernel<YT>, dim3(rg, batch), dim3(256), 0, st, p);
     CRG_CHECK_LAUNCH(ctx, "splitk_reduce");
   }
@@ -663,25 +709,25 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch) {
 }
 
 template <int NSPLIT, typename AT, typename YT, bool CONV>
-int launch_wnt(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch) {
+int launch_wnt(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   // 160-wide tiles when they divide N (all UNet widths are multiples of 320), else 128-wide.
   const bool geglu = p.epi == CRG_EPI_GEGLU;
-  if (!geglu && p.N <= 32) return launch<1, NSPLIT, AT, YT, CONV>(ctx, st, p, batch);  // conv_out-like thin outputs
-  if (!geglu && p.N % 160 == 0) return launch<5, NSPLIT, AT, YT, CONV>(ctx, st, p, batch);
-  return launch<4, NSPLIT, AT, YT, CONV>(ctx, st, p, batch);
+  if (!geglu && p.N <= 32) return launch<1, NSPLIT, AT, YT, CONV>(ctx, st, p, batch, wk);  // conv_out-like thin outputs
+  if (!geglu && p.N % 160 == 0) return launch<5, NSPLIT, AT, YT, CONV>(ctx, st, p, batch, wk);
+  return launch<4, NSPLIT, AT, YT, CONV>(ctx, st, p, batch, wk);
 }
 
 template <bool CONV>
-int dispatch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, int a_dtype, int y_dtype, int prec) {
+int dispatch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, int a_dtype, int y_dtype, int prec, Work wk) {
   if (prec == CRG_PREC_BF16) {
-    if (a_dtype == CRG_BF16 && y_dtype == CRG_BF16) return launch_wnt<1, bf16, bf16, CONV>(ctx, st, p, batch);
-    if (a_dtype == CRG_BF16 && y_dtype == CRG_F32) return launch_wnt<1, bf16, float, CONV>(ctx, st, p, batch);
-    if (a_dtype == CRG_F32 && y_dtype == CRG_BF16) return launch_wnt<1, float, bf16, CONV>(ctx, st, p, batch);
-    if (a_dtype == CRG_F32 && y_dtype == CRG_F32) return launch_wnt<1, float, float, CONV>(ctx, st, p, batch);
+    if (a_dtype == CRG_BF16 && y_dtype == CRG_BF16) return launch_wnt<1, bf16, bf16, CONV>(ctx, st, p, batch, wk);
+    if (a_dtype == CRG_BF16 && y_dtype == CRG_F32) return launch_wnt<1, bf16, float, CONV>(ctx, st, p, batch, wk);
+    if (a_dtype == CRG_F32 && y_dtype == CRG_BF16) return launch_wnt<1, float, bf16, CONV>(ctx, st, p, batch, wk);
+    if (a_dtype == CRG_F32 && y_dtype == CRG_F32) return launch_wnt<1, float, float, CONV>(ctx, st, p, batch, wk);
   } else if (prec == CRG_PREC_BF16X3) {
-    if (a_dtype == CRG_F32 && y_dtype == CRG_F32) return launch_wnt<2, float, float, CONV>(ctx, st, p, batch);
+    if (a_dtype == CRG_F32 && y_dtype == CRG_F32) return launch_wnt<2, float, float, CONV>(ctx, st, p, batch, wk);
     if (!CONV && a_dtype == CRG_BF16 && y_dtype == CRG_F32 && p.a_is_weight)
-      return launch_wnt<2, bf16, float, false>(ctx, st, p, batch);
+      return launch_wnt<2, bf16, float, false>(ctx, st, p, batch, wk);
   }
   return crg_fail(ctx, -22, "gemm/conv: unsupported dtype/precision combination a=%d y=%d prec=%d", a_dtype, y_dtype, prec);
 }
@@ -713,8 +759,8 @@ extern "C" int crg_gemm(crg_ctx* ctx, void* stream, const crg_gemm_args* a) {
   const double flops = 2.0 * a->M * (double)a->N * a->K * a->batch;
   const double bytes = ((double)a->M * a->K * crg_dtype_size(a->a_dtype) + (double)a->N * a->K * 2 +
                         (double)a->M * a->N * crg_dtype_size(a->y_dtype) * (a->residual ? 2 : 1)) * a->batch;
-  crg_prof_scope ps(ctx, (hipStream_t)stream, CRG_K_GEMM, flops, bytes);
-  return dispatch<false>(ctx, (hipStream_t)stream, p, a->batch, a->a_dtype, a->y_dtype, a->prec);
+  return dispatch<false>(ctx, (hipStream_t)stream, p, a->batch, a->a_dtype, a->y_dtype, a->prec,
+                         Work{flops, bytes, (double)a->M * a->K * crg_dtype_size(a->a_dtype), (double)a->N * a->K * 2});
 }
 
 extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
@@ -745,6 +791,6 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
   const double flops = 2.0 * p.M * (double)p.N * p.K;
   const double bytes = (double)a->N * a->H * a->W * Ctot * crg_dtype_size(a->x_dtype) + (double)p.N * p.K * 2 +
                        (double)p.M * p.N * crg_dtype_size(a->y_dtype) * (a->residual ? 2 : 1);
-  crg_prof_scope ps(ctx, (hipStream_t)stream, CRG_K_CONV, flops, bytes);
-  return dispatch<true>(ctx, (hipStream_t)stream, p, 1, a->x_dtype, a->y_dtype, a->prec);
+  return dispatch<true>(ctx, (hipStream_t)stream, p, 1, a->x_dtype, a->y_dtype, a->prec,
+                        Work{flops, bytes, (double)a->N * a->H * a->W * Ctot * crg_dtype_size(a->x_dtype), (double)p.N * p.K * 2});
 }

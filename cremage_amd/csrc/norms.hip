@@ -299,16 +299,22 @@ extern "C" int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const vo
   hipStream_t st = (hipStream_t)stream;
   const double elems = (double)N * HW * C;
   const size_t es = crg_dtype_size(dtype);
-  crg_prof_scope ps(ctx, st, CRG_K_GROUPNORM, 8.0 * elems, elems * es * 3);
   dim3 grid(chunks, N);
-  if (dtype == CRG_BF16) {
-    hipLaunchKernelGGL(gn_stats_kernel<bf16>, grid, dim3(threads), 0, st, (const bf16*)x, (const bf16*)x2, C1, C, HW, groups, rpc, part, kbuf);
-    hipLaunchKernelGGL(gn_apply_kernel<bf16>, grid, dim3(threads), 0, st, (const bf16*)x, (const bf16*)x2, C1, C, HW, groups, rpc, chunks,
-                       part, kbuf, gamma, beta, eps, fuse_silu, (bf16*)y);
-  } else {
-    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(threads), 0, st, (const float*)x, (const float*)x2, C1, C, HW, groups, rpc, part, kbuf);
-    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(threads), 0, st, (const float*)x, (const float*)x2, C1, C, HW, groups, rpc, chunks,
-                       part, kbuf, gamma, beta, eps, fuse_silu, (float*)y);
+  {
+    crg_prof_scope ps(ctx, st, CRG_K_GN_STATS, 3.0 * elems, elems * es);
+    if (dtype == CRG_BF16)
+      hipLaunchKernelGGL(gn_stats_kernel<bf16>, grid, dim3(threads), 0, st, (const bf16*)x, (const bf16*)x2, C1, C, HW, groups, rpc, part, kbuf);
+    else
+      hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(threads), 0, st, (const float*)x, (const float*)x2, C1, C, HW, groups, rpc, part, kbuf);
+  }
+  {
+    crg_prof_scope ps(ctx, st, CRG_K_GN_APPLY, 5.0 * elems, elems * es * 2);
+    if (dtype == CRG_BF16)
+      hipLaunchKernelGGL(gn_apply_kernel<bf16>, grid, dim3(threads), 0, st, (const bf16*)x, (const bf16*)x2, C1, C, HW, groups, rpc, chunks,
+                         part, kbuf, gamma, beta, eps, fuse_silu, (bf16*)y);
+    else
+      hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(threads), 0, st, (const float*)x, (const float*)x2, C1, C, HW, groups, rpc, chunks,
+                         part, kbuf, gamma, beta, eps, fuse_silu, (float*)y);
   }
   CRG_CHECK_LAUNCH(ctx, "groupnorm");
   return 0;

@@ -493,8 +493,9 @@ def axpby_(y: torch.Tensor, x: torch.Tensor, a: float, b: float = 1.0) -> torch.
 
 # ---------------------------------------------------------------------------------- profiling
 class profile:
-    """Context manager: per-kernel-family device time (HIP events on the launch stream) + algorithmic
-    FLOPs/bytes of every crg_* launch issued inside it (bench.py's `roofline`)."""
+    """Context manager: per-kernel device time (HIP events on the launch stream) + algorithmic FLOPs/bytes of
+    every kernel launched by crg_* calls inside it (bench.py's `roofline`).  `kernels` is keyed by kernel slot
+    (one per kernel symbol, with its rocprofv3 name), `result` sums the slots into families."""
 
     def __init__(self, device=None):
         self.dev = torch.cuda.current_device() if device is None else device
@@ -509,6 +510,13 @@ class profile:
         h = L.ctx(self.dev)
         p = L.Profile()
         L.check(L.load().crg_profile_end(h, _st(), C.byref(p)), h, "crg_profile_end")
-        self.result = {L.FAMILY_NAMES[i]: dict(ms=p.ms[i], flops=p.flops[i], bytes=p.bytes[i], launches=p.launches[i])
-                       for i in range(L.K_FAMILIES)}
+        lib = L.load()
+        self.kernels = {L.SLOT_NAMES[i]: dict(ms=p.ms[i], flops=p.flops[i], bytes=p.bytes[i], launches=p.launches[i],
+                                              symbol=lib.crg_kernel_name(i).decode(), family=L.SLOT_FAMILY[i])
+                        for i in range(L.K_SLOTS)}
+        self.result = {}
+        for k in self.kernels.values():
+            f = self.result.setdefault(k["family"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            for key in ("ms", "flops", "bytes", "launches"):
+                f[key] += k[key]
         return False

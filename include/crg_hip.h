@@ -59,18 +59,25 @@ const char* crg_last_error(crg_ctx* ctx);
 int crg_ctx_reserve(crg_ctx* ctx, size_t bytes);
 
 /* ---- per-kernel timing (bench.py roofline: HIP events on the launch stream) ------------ */
-/* Between begin/end every crg_* launch is bracketed by hipEvents and tagged with its kernel
- * family and algorithmic FLOPs/bytes.  crg_profile_end synchronises and fills `out`. */
-enum crg_kernel_family {
-  CRG_K_GEMM = 0, CRG_K_CONV = 1, CRG_K_ATTN = 2, CRG_K_GROUPNORM = 3, CRG_K_LAYERNORM = 4,
-  CRG_K_ELEMENTWISE = 5, CRG_K_CONV_SMALL = 6, CRG_K_SOFTMAX = 7, CRG_K_FAMILIES = 8
+/* Between begin/end every kernel launched by a crg_* call is bracketed by hipEvents on its launch stream and
+ * tagged with its kernel slot (one slot per kernel symbol as rocprofv3 prints it, see crg_kernel_name) and the
+ * algorithmic FLOPs / bytes of the call.  crg_profile_end synchronises and fills `out`. */
+enum crg_kernel_slot {
+  CRG_K_GEMM_W1 = 0, CRG_K_GEMM_W4 = 1, CRG_K_GEMM_W5 = 2, /* gemm_glds_kernel<WNT, *, CONV=false>  bf16 LDS-DMA GEMM      */
+  CRG_K_GEMM_X3 = 3,                                        /* gemm_kernel<*, *, *, *, false>        fp32 / split-bf16 GEMM */
+  CRG_K_CONV_W1 = 4, CRG_K_CONV_W4 = 5, CRG_K_CONV_W5 = 6, /* gemm_glds_kernel<WNT, *, CONV=true>   bf16 implicit-GEMM conv */
+  CRG_K_CONV_X3 = 7,                                        /* gemm_kernel<*, *, *, *, true>         fp32-class conv (VAE)  */
+  CRG_K_SPLITK = 8, CRG_K_ATTN = 9, CRG_K_GN_STATS = 10, CRG_K_GN_APPLY = 11, CRG_K_LAYERNORM = 12,
+  CRG_K_ELEMENTWISE = 13, CRG_K_CONV_SMALL = 14, CRG_K_SOFTMAX = 15, CRG_K_SLOTS = 16
 };
 typedef struct {
-  double ms[CRG_K_FAMILIES];     /* summed device time per family               */
-  double flops[CRG_K_FAMILIES];  /* summed algorithmic FLOPs (2*MAC)            */
-  double bytes[CRG_K_FAMILIES];  /* summed algorithmic (minimum) HBM bytes      */
-  int64_t launches[CRG_K_FAMILIES];
+  double ms[CRG_K_SLOTS];     /* summed device time per kernel slot          */
+  double flops[CRG_K_SLOTS];  /* summed algorithmic FLOPs (2*MAC)            */
+  double bytes[CRG_K_SLOTS];  /* summed algorithmic (minimum) HBM bytes      */
+  int64_t launches[CRG_K_SLOTS];
 } crg_profile;
+/* Kernel symbol (as it appears in a rocprofv3 kernel trace, template arguments abbreviated) of a slot. */
+const char* crg_kernel_name(int slot);
 int crg_profile_begin(crg_ctx* ctx);
 int crg_profile_end(crg_ctx* ctx, void* stream, crg_profile* out);
 

@@ -11,8 +11,10 @@ a = ap.parse_args()
 dev = "cuda:0"
 torch.manual_seed(0)
 shapes = {
-    "conv": [(8, 320, 64, 320), (8, 640, 32, 640), (8, 1280, 16, 1280), (8, 640, 64, 320)],
-    "gemm": [(32768, 320, 2880), (32768, 2560, 320), (8192, 640, 640), (8192, 5120, 640), (2048, 1280, 1280), (32768, 320, 320)],
+    "conv": [(8, 320, 64, 320), (8, 640, 32, 640), (8, 1280, 16, 1280), (8, 640, 64, 320), (8, 1280, 8, 1280), (8, 2560, 16, 1280),
+             (8, 1280, 32, 640)],
+    "gemm": [(32768, 320, 2880), (32768, 2560, 320), (8192, 640, 640), (8192, 5120, 640), (2048, 1280, 1280), (32768, 320, 320),
+             (2048, 10240, 1280), (2048, 1280, 5120), (512, 10240, 1280), (512, 1280, 5120), (8192, 640, 2560)],
 }[a.kind]
 for sh in shapes:
     if a.kind == "conv":
@@ -38,4 +40,4 @@ for sh in shapes:
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / a.reps
-    print(f"{a.kind} {sh}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF   (CRG_GEMM8={os.environ.get('CRG_GEMM8')})", flush=True)
+    print(f"{a.kind} {sh}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF   (XCD_PART={os.environ.get('CRG_XCD_PART')} SPLIT_BELOW={os.environ.get('CRG_SPLIT_BELOW')})", flush=True)

@@ -28,6 +28,23 @@ def demangle(names):
         return {n: n for n in names}
 
 
+def slot_of(name):
+    """rocprofv3 kernel name (mangled, or mis-demangled: its demangler prints `__bf16, true` as `bool _Accum, bool, E`)
+    -> cremage_amd._lib.SLOT_NAMES entry (enum crg_kernel_slot), or None for kernels that are not ours."""
+    import re
+    m = re.search(r"gemm_glds_kernel(?:<|ILi)(\d)", name)
+    if m:
+        conv = ("Lb1E" in name) or ("bool _Accum" in name) or (", true>" in name)
+        return ("conv_w" if conv else "gemm_w") + m.group(1)
+    if "gemm_kernel" in name:
+        return "conv_x3" if (("Lb1E" in name) or (", true>" in name)) else "gemm_x3"
+    for pat, slot in (("splitk_reduce", "splitk_reduce"), ("attn_kernel", "attention"), ("gn_stats", "gn_stats"), ("gn_apply", "gn_apply"),
+                      ("layernorm_kernel", "layernorm"), ("softmax_rows", "softmax"), ("conv_small", "conv_small")):
+        if pat in name:
+            return slot
+    return None
+
+
 def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
     return n.split("(")[0][:90]
@@ -75,11 +92,37 @@ def main():
             mb = (2 * fl + wl) * 1024 / 1e6
             traffic[short(dm2[k])] = dict(launches=f[k][1], fetch_kib_raw=fl, write_kib=wl, hbm_bytes_per_launch=(2 * fl + wl) * 1024)
             out.append(f"| `{short(dm2[k])}` | {f[k][1]} | {fl:.1f} | {wl:.1f} | {mb:.2f} |")
+    # per kernel slot (the unit bench.py's `roofline` reports): calls / avg duration from the stats pass, HBM bytes from the PMC passes
+    by_slot = collections.defaultdict(lambda: dict(calls=0, total_ms=0.0, fetch_kib=0.0, write_kib=0.0, pmc_launches=0))
+    for r in rows:
+        sl = slot_of(r["Name"])
+        if sl:
+            by_slot[sl]["calls"] += int(r["Calls"])
+            by_slot[sl]["total_ms"] += float(r["TotalDurationNs"]) / 1e6
+    if a.fetch and a.write:
+        for k, (v, n) in f.items():
+            sl = slot_of(k)
+            if sl:
+                by_slot[sl]["fetch_kib"] += v
+                by_slot[sl]["pmc_launches"] += n
+        for k, (v, n) in w.items():
+            sl = slot_of(k)
+            if sl:
+                by_slot[sl]["write_kib"] += v
+    out += ["", "## Per kernel slot (enum crg_kernel_slot; what bench.py's `roofline` reports)", "",
+            "| slot | calls | total ms | avg us | HBM MB/launch (PMC, corrected) |", "|---|---:|---:|---:|---:|"]
+    slots_json = {}
+    for sl, e in sorted(by_slot.items(), key=lambda kv: -kv[1]["total_ms"]):
+        hb = (2 * e["fetch_kib"] + e["write_kib"]) * 1024 / e["pmc_launches"] if e["pmc_launches"] else None
+        slots_json[sl] = dict(calls=e["calls"], total_ms=round(e["total_ms"], 3), avg_us=round(1e3 * e["total_ms"] / max(1, e["calls"]), 2),
+                              hbm_bytes_per_launch=hb)
+        out.append(f"| {sl} | {e['calls']} | {e['total_ms']:.2f} | {1e3 * e['total_ms'] / max(1, e['calls']):.1f} | {'' if hb is None else f'{hb / 1e6:.2f}'} |")
     os.makedirs(os.path.join(REPO, "profiles"), exist_ok=True)
+    json.dump(slots_json, open(os.path.join(REPO, "profiles", f"{a.round}_by_slot.json"), "w"), indent=1)
     open(os.path.join(REPO, "profiles", f"{a.round}_rocprof_summary.md"), "w").write("\n".join(out) + "\n")
     if traffic:
         json.dump(traffic, open(os.path.join(REPO, "profiles", f"{a.round}_traffic.json"), "w"), indent=1)
-    print("\n".join(out[-22:]))
+    print("\n".join(out[-40:]))
 
 
 if __name__ == "__main__":
