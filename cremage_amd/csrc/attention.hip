@@ -30,7 +30,7 @@ struct AttnP {
 
 constexpr int VROW = 136;  // bytes per V^T LDS row (64 keys * 2 B + 8 pad)
 
-template <int KS, int NV>
+template <int KS, int NV, bool ONES>
 __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_kernel(AttnP p) {
   constexpr int KROW = KS * 32 + 16;  // bytes per K LDS row
   constexpr int KCH = 2 * KS;         // 16-byte chunks per K row
@@ -56,8 +56,9 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
   const bf16x8 ones8 = {one, one, one, one, one, one, one, one};
   // Row-sum trick: when the padded head dim has a spare V^T row (Dh < NV*32), row Dh of the V^T tile is
   // all ones, so O^T[Dh][q] accumulates sum_k P[q][k] on the matrix core: the softmax denominator costs
-  // no VALU adds.  (Masked keys have P = 0 exactly, so the ones may cover them too.)
-  const bool ones_row = p.Dh < NV * 32;
+  // no VALU adds.  (Masked keys have P = 0 exactly, so the ones may cover them too.)  ONES == (Dh < NV*32), chosen by
+  // the launcher so that the row-sum adds are compiled out of the VALU-bound loop.
+  constexpr bool ones_row = ONES;
 
   // ---- Q fragments (B operand): lane (r, hh) holds Q[q0 + r][16 s + 8 hh + j] ----
   bf16x8 qf[KS];
@@ -99,6 +100,14 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
   }
   auto prefetch = [&](int tile) {
     const int kbase = tile * 64;
+    if (kbase + 64 <= p.Nk) {  // interior tile (block-uniform): no per-key bounds checks
+#pragma unroll
+      for (int i = 0; i < KLOADS; ++i) kreg[i] = kuse[i] ? *reinterpret_cast<const bf16x8*>(kptr[i] + (long)kbase * p.ldk) : zero8;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        vreg[i] = vmode[i] == 1 ? *reinterpret_cast<const bf16x8*>(vptr[i] + kbase) : (vmode[i] == 2 ? ones8 : zero8);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < KLOADS; ++i) {
       const int row = (t + 256 * i) / KCH;
@@ -174,9 +183,11 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
           if (key >= p.Nk) st[kb][e] = -INFINITY;
         }
     }
-    float mx = fmaxf(st[0][0], st[1][0]);
+    // 32 scores -> 16 v_max3_f32: max3(a, b, c) chains, two new values per instruction
+    float mx = fmaxf(fmaxf(st[0][0], st[1][0]), st[0][1]);
 #pragma unroll
-    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(st[0][e], st[1][e]));
+    for (int e = 1; e < 15; ++e) mx = fmaxf(fmaxf(mx, st[1][e]), st[0][e + 1]);
+    mx = fmaxf(mx, st[1][15]);
     mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;
     const float m_new = fmaxf(m_run, mx);
     if (__any(m_new != m_run)) {  // wave-uniform: rescale only when some row's running max moved (alpha == 1 otherwise)
@@ -190,13 +201,15 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
     }
     float rs = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < 2; ++kb) {
+      st[kb] = st[kb] * p.scale_log2 - m_run;  // whole-vector form: contracts to v_pk_fma_f32 (two scores per instruction)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][e], p.scale_log2, -m_run));
+        const float pe = __builtin_amdgcn_exp2f(st[kb][e]);
         st[kb][e] = pe;
         if (!ones_row) rs += pe;
       }
+    }
     if (!ones_row) l_run += rs;
     // ---- P^T fragments straight from the accumulator registers ----
     bf16x8 pf[2][2];
@@ -262,7 +275,8 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
 template <int KS, int NV>
 int launch_attn(crg_ctx* ctx, hipStream_t st, const AttnP& p) {
   dim3 grid((p.Nq + 127) / 128, p.B * p.H);
-  hipLaunchKernelGGL((attn_kernel<KS, NV>), grid, dim3(256), 0, st, p);
+  if (p.Dh < NV * 32) hipLaunchKernelGGL((attn_kernel<KS, NV, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((attn_kernel<KS, NV, false>), grid, dim3(256), 0, st, p);
   CRG_CHECK_LAUNCH(ctx, "attention");
   return 0;
 }

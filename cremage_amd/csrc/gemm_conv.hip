@@ -87,14 +87,15 @@ __device__ __forceinline__ bf16x8 split_hi(const crg_vec8<float>& v, bf16x8& lo)
 }
 
 // ---- shared epilogue: lane holds rows n = ..+fq*4+{0..3}, column m = ..+frow of each 16x16 tile ----
-template <int WNT, typename YT>
-__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][4], int m0, int n0, int wm, int wn, int frow, int fq,
-                                              int bz, int sid, const bf16x4 (&pre)[WNT][4], bool use_pre) {
+template <int WNT, typename YT, int WMT = 4>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][WMT], int m0, int n0, int wm, int wn, int frow, int fq,
+                                              int bz, int sid, const bf16x4 (&pre)[WNT][WMT], bool use_pre,
+                                              const f32x4 (&bpre)[WNT], bool use_bpre) {
   if (p.splits > 1) {
     float* S = p.slab + ((long)bz * p.splits + sid) * p.M * p.N;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + wm * 64 + j * 16 + frow;
+    for (int j = 0; j < WMT; ++j) {
+      const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
       if (m >= p.M) continue;
 #pragma unroll
       for (int i = 0; i < WNT; ++i) {
@@ -111,8 +112,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][
   YT* Y = reinterpret_cast<YT*>(p.y) + (long)bz * p.y_bs;
   const YT* R = p.res ? reinterpret_cast<const YT*>(p.res) + (long)bz * p.r_bs : nullptr;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + wm * 64 + j * 16 + frow;
+  for (int j = 0; j < WMT; ++j) {
+    const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
     if (m >= p.M) continue;
     const float brow = (p.bias_mode == CRG_BIAS_ROW) ? p.bias[m] : 0.f;
     const float* cv = p.cvec ? p.cvec + (long)(m / p.cvec_rows) * p.cvec_ld : nullptr;
@@ -146,7 +147,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][
       f32x4 v = acc[i][j];
       const bool full = (n + 4 <= p.N);
       if (full) {
-        if (p.bias_mode == CRG_BIAS_COL) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (use_bpre) v += bpre[i];
+        else if (p.bias_mode == CRG_BIAS_COL) v += *reinterpret_cast<const f32x4*>(p.bias + n);
         else if (p.bias_mode == CRG_BIAS_ROW) v += brow;
         if (p.epi == CRG_EPI_SILU) {
 #pragma unroll
@@ -395,7 +397,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   }
 
   const bf16x4 no_pre[WNT][4] = {};
-  gemm_epilogue<WNT, YT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid, no_pre, false);
+  const f32x4 no_bias[WNT] = {};
+  gemm_epilogue<WNT, YT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid, no_pre, false, no_bias, false);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -404,14 +407,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 // cycles per wave-instruction (MI355X_MICROARCH.md §LDS), which made the register-staged kernel LDS-bound.
 // One wave-instruction writes 1 KiB = 8 rows x 128 B, lane-linear; the XOR swizzle of the 16-byte chunk is
 // applied on the per-lane SOURCE address (guide rule 21).  Out-of-image taps / tile tails read a 16-byte zero
-// page instead, which gives the zero padding for free.  k-tile t+1 is issued before the MFMAs of tile t; the
-// __syncthreads() at the end of the iteration (vmcnt(0) + barrier) retires it.
-template <int WNT, typename YT, bool CONV>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
+// page instead, which gives the zero padding for free.
+// Pipeline: a ring of STAGES LDS buffers, k-tiles t+1 .. t+STAGES-1 in flight while tile t is multiplied.  Each wave
+// waits for ITS OWN loads of tile t with a counted s_waitcnt vmcnt (loads retire in order, so "all but the newest
+// (STAGES-2) tiles' worth"), then one s_barrier makes every wave's part of tile t visible and proves that everybody is
+// done reading the buffer of tile t-1, which is the one the next DMA batch overwrites.  STAGES = 2 keeps two blocks per
+// CU (2 x 74 KB); grids that cannot put two blocks on a CU anyway run STAGES = 4 (147 KB) so that a lone block still
+// covers the ~1.5 us global -> LDS latency.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {  // s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields left at "no wait")
+  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+
+template <int WNT, typename YT, bool CONV, int STAGES, int WMT, int KG>
+__global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
+  // Block tile (32*WMT) x (32*WNT) x 64; 4*KG waves.  The 4 waves of a k-group tile the block 2 x 2 (each 16*WMT rows x
+  // 16*WNT columns); with KG == 2 the second group multiplies the second 32-wide k-step of every k-tile (in-block
+  // split-K: twice the waves per SIMD on the same LDS traffic - for grids that cannot put two blocks on a CU) and its
+  // accumulators are folded into group 0 through LDS before the epilogue.
+  constexpr int BMT = 32 * WMT;
   constexpr int BN = 32 * WNT;
-  constexpr int XS_BYTES = BM * 128;
+  constexpr int NW = 4 * KG;
+  constexpr int XS_BYTES = BMT * 128;
   constexpr int WS_BYTES = BN * 128;
   constexpr int STAGE_BYTES = XS_BYTES + WS_BYTES;
+  constexpr int XRG = BMT / 8, WRG = BN / 8;      // 8-row groups (one 1 KiB wave-instruction each)
+  constexpr int XL = (XRG + NW - 1) / NW;         // DMA instructions per wave per k-tile (uniform: waves without a row
+  constexpr int WL = (WRG + NW - 1) / NW;         // group left issue a dummy load so that vmcnt counts stay uniform)
+  constexpr int DUMMY = STAGES * STAGE_BYTES;     // 1 KiB scratch target of the dummy loads
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -419,29 +443,30 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int kg = wave >> 2;  // k-group of this wave
+  const int wm = (wave & 3) >> 1, wn = wave & 1;
 
   int tile_m, tile_n, sid;
   block_to_tile(p, tile_m, tile_n, sid);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * BMT, n0 = tile_n * BN;
   const int bz = blockIdx.y;
 
   const bf16* A = reinterpret_cast<const bf16*>(p.a) + (long)bz * p.a_bs;
   const bf16* Wp = p.w + (long)bz * p.w_bs;
   const bf16* zpage = p.zero_page;
 
-  // this lane always stages LDS row (8*j + lane/8), physical chunk lane%8 of wave-instruction j = wave + 4q;
+  // this lane always stages LDS row (8*g + lane/8), physical chunk lane%8 of row group g = wave + NW*q;
   // the data it carries is logical chunk clog = (lane%8) ^ (row%8)
   const int rsub = lane >> 3;
   const int clog = (lane & 7) ^ rsub;
 
-  long xrow_off[4];
-  int xh[4], xw[4];
-  bool xok[4];
+  long xrow_off[XL];
+  int xh[XL], xw[XL];
+  bool xok[XL];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int m = m0 + (wave + 4 * q) * 8 + rsub;
-    xok[q] = m < p.M;
+  for (int q = 0; q < XL; ++q) {
+    const int m = m0 + (wave + NW * q) * 8 + rsub;
+    xok[q] = m < p.M && (wave + NW * q) < XRG;
     if (CONV) {
       const int hw = p.Ho * p.Wo;
       const int img = m / hw;
@@ -456,12 +481,12 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
       xh[q] = xw[q] = 0;
     }
   }
-  bool wok[WNT];
-  long wrow_off[WNT];
+  bool wok[WL];
+  long wrow_off[WL];
 #pragma unroll
-  for (int q = 0; q < WNT; ++q) {
-    const int n = n0 + (wave + 4 * q) * 8 + rsub;
-    wok[q] = n < p.N;
+  for (int q = 0; q < WL; ++q) {
+    const int n = n0 + (wave + NW * q) * 8 + rsub;
+    wok[q] = n < p.N && (wave + NW * q) < WRG;
     wrow_off[q] = (long)n * p.ldw;
   }
 
@@ -496,24 +521,27 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
       const int Cs = second ? p.C2 : p.C1;
       const int cs = second ? cch - p.C1 : cch;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < XL; ++q) {
         const int hv = xh[q] + kh, wv = xw[q] + kw;
         const bool ok = kok && xok[q] && (unsigned)hv < (unsigned)Hv && (unsigned)wv < (unsigned)Wv;
         const int hs = p.up ? hv >> 1 : hv, wsrc = p.up ? wv >> 1 : wv;
         const bf16* src = ok ? base + (xrow_off[q] + (long)hs * p.W + wsrc) * Cs + cs : zpage;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + (wave + 4 * q) * 1024), 16, 0, 0);
+        char* dst = (wave + NW * q) < XRG ? xs + (wave + NW * q) * 1024 : smem + DUMMY;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < XL; ++q) {
         const bf16* src = (kok && xok[q]) ? A + xrow_off[q] + kc : zpage;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + (wave + 4 * q) * 1024), 16, 0, 0);
+        char* dst = (wave + NW * q) < XRG ? xs + (wave + NW * q) * 1024 : smem + DUMMY;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
       }
     }
 #pragma unroll
-    for (int q = 0; q < WNT; ++q) {
+    for (int q = 0; q < WL; ++q) {
       const bf16* src = (kok && wok[q]) ? Wp + wrow_off[q] + kc : zpage;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ws + (wave + 4 * q) * 1024), 16, 0, 0);
+      char* dst = (wave + NW * q) < WRG ? ws + (wave + NW * q) * 1024 : smem + DUMMY;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
     }
     // advance to the next k-tile
     kc += BK;
@@ -533,24 +561,23 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
     }
   };
 
-  f32x4 acc[WNT][4];
+  f32x4 acc[WNT][WMT];
 #pragma unroll
   for (int i = 0; i < WNT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  stage(kt_begin & 1);
+    for (int j = 0; j < WMT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15;
   const int fq = lane >> 4;
-  // residual tile of this lane, fetched now so that its latency hides under the whole K loop (bf16 outputs)
-  bf16x4 rres[WNT][4];
+  // residual tile of this lane, fetched first so that its latency hides under the whole K loop (bf16 outputs); being the
+  // oldest loads in flight they are retired by the first counted wait
+  bf16x4 rres[WNT][WMT];
   const bool pre_res = sizeof(YT) == 2 && p.res && p.splits == 1 && (p.ldr & 3) == 0 && p.epi != CRG_EPI_GEGLU;
-  if (pre_res) {
+  if (pre_res && kg == 0) {
     const bf16* R = reinterpret_cast<const bf16*>(p.res) + (long)bz * p.r_bs;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + wm * 64 + j * 16 + frow;
+    for (int j = 0; j < WMT; ++j) {
+      const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
 #pragma unroll
       for (int i = 0; i < WNT; ++i) {
         const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
@@ -558,27 +585,72 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
       }
     }
   }
-  __syncthreads();
 
+  // column bias of this lane's 4-wide output groups: also fetched ahead of the K loop (a lone block per CU would otherwise
+  // pay a full global-load latency between its last MFMA and its first store)
+  f32x4 bpre[WNT];
+  const bool pre_bias = p.bias_mode == CRG_BIAS_COL && p.splits == 1 && p.epi != CRG_EPI_GEGLU;
+  if (pre_bias && kg == 0) {
+#pragma unroll
+    for (int i = 0; i < WNT; ++i) {
+      const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
+      bpre[i] = n + 4 <= p.N ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  constexpr int LOADS = XL + WL;  // LDS-DMA instructions per wave per k-tile
+  constexpr int D = STAGES - 1;   // prefetch distance
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (kt_begin + s < nk) stage(s);
+
+  int buf = 0, nbuf = D;  // ring positions of tile kt and of tile kt + D
   for (int kt = kt_begin; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage((kt + 1) & 1);
-    const char* xs = smem + (kt & 1) * STAGE_BYTES;
+    const int newer = nk - 1 - kt;  // tiles issued after tile kt that may stay in flight (at most D - 1)
+    if (D >= 3 && newer >= 2) wait_vmcnt<(D >= 3 ? 2 : 0) * LOADS>();
+    else if (D >= 2 && newer >= 1) wait_vmcnt<(D >= 2 ? 1 : 0) * LOADS>();
+    else wait_vmcnt<0>();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + D < nk) stage(nbuf);
+    const char* xs = smem + buf * STAGE_BYTES;
     const char* ws = xs + XS_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 xf[4], wf[WNT];
+    for (int k2 = 0; k2 < 2 / KG; ++k2) {
+      const int ks = KG == 2 ? kg : k2;
+      bf16x8 xf[WMT], wf[WNT];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xs + lds_off(wm * 64 + j * 16 + frow, ks * 4 + fq));
+      for (int j = 0; j < WMT; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xs + lds_off(wm * (16 * WMT) + j * 16 + frow, ks * 4 + fq));
 #pragma unroll
       for (int i = 0; i < WNT; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(ws + lds_off(wn * (16 * WNT) + i * 16 + frow, ks * 4 + fq));
 #pragma unroll
       for (int i = 0; i < WNT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WMT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+    nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
+  }
+  if constexpr (KG == 2) {
+    // fold the second k-group's partial tile into the first: [wave&3][i][j][lane] f32x4 in the (now idle) ring
+    static_assert(4 * WNT * WMT * 64 * 16 <= STAGES * STAGE_BYTES, "reduction buffer must fit in the DMA ring");
+    __syncthreads();  // every wave is done reading the ring (all DMA batches were retired by the last counted wait)
+    f32x4* red = reinterpret_cast<f32x4*>(smem) + ((wave & 3) * WNT * WMT) * 64 + lane;
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < WNT; ++i)
+#pragma unroll
+        for (int j = 0; j < WMT; ++j) red[(i * WMT + j) * 64] = acc[i][j];
     }
     __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int i = 0; i < WNT; ++i)
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) acc[i][j] += red[(i * WMT + j) * 64];
   }
-  gemm_epilogue<WNT, YT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid, rres, pre_res);
+  gemm_epilogue<WNT, YT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid, rres, pre_res, bpre, pre_bias);
 }
 
 // Split-K second pass: y = epi(sum_s slab[s] + bias) + cvec + residual, 4 consecutive n per thread.
@@ -634,6 +706,7 @@ inline int choose_splits(const GemmP& p, int tiles, int batch) {
   // 256..511 blocks leave one block (4 waves) on most CUs, which hides neither the barrier nor the DMA latency: cut K in
   // two when it is long enough to amortise the slab pass (measured: 8x32x32 640->640 conv 112 -> 89 us, 1280->640 203 -> 137 us;
   // K = 2560 GEMMs lose 5 %, hence the nk bound)
+  // short K (nk < 24) is not split: measured slower than the 64-row / 8-wave configuration on the unsplit problem
   if (blocks >= 512 || nk < 24 || (blocks >= 256 && nk < 64)) return 1;
   int s = (int)((512 + blocks - 1) / blocks);
   if (s > nk / 8) s = nk / 8;
@@ -664,42 +737,73 @@ inline void choose_xcd_partition(GemmP& p, const Work& wk) {
   }
 }
 
+template <int WNT, int NSPLIT, typename AT, typename YT, bool CONV, int STAGES, int WMT, int KG>
+int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
+  constexpr int BN = 32 * WNT;
+  constexpr bool GLDS = (NSPLIT == 1) && (sizeof(AT) == 2);
+  constexpr size_t lds = GLDS ? (size_t)STAGES * (32 * WMT + BN) * 128 + 1024 /* dummy-load target */ : (size_t)2 * NSPLIT * (BM + BN) * 128;
+  void (*kern)(GemmP);
+  if constexpr (GLDS) kern = gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG>;
+  else kern = gemm_kernel<WNT, NSPLIT, AT, YT, CONV>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", lds, hipGetErrorString(e));
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_n * p.tiles_m * p.splits, batch, 1);
+  constexpr int slot = !GLDS ? (CONV ? CRG_K_CONV_X3 : CRG_K_GEMM_X3)
+                             : (CONV ? (WNT == 5 ? CRG_K_CONV_W5 : WNT == 4 ? CRG_K_CONV_W4 : CRG_K_CONV_W1)
+                                     : (WNT == 5 ? CRG_K_GEMM_W5 : WNT == 4 ? CRG_K_GEMM_W4 : CRG_K_GEMM_W1));
+  crg_prof_scope ps(ctx, st, slot, wk.flops, wk.bytes);
+  hipLaunchKernelGGL(kern, grid, dim3(GLDS ? 256 * KG : 256), lds, st, p);
+  CRG_CHECK_LAUNCH(ctx, "gemm");
+  return 0;
+}
+
+// Tile / pipeline configuration of the LDS-DMA kernel, by how many blocks the problem yields (256 CUs):
+//   A  128 x BN tile, 4 waves, 2-deep ring   : >= ~1.5 blocks per CU; two blocks share a CU and hide each other's latencies
+//   B  128 x BN tile, 8 waves (in-block split-K), 3-deep ring : about one block per CU
+//   C   64 x BN tile, 8 waves, 4-deep ring   : few 128-row tiles (16x16 / 8x8 levels): twice the blocks, all CUs busy
 template <int WNT, int NSPLIT, typename AT, typename YT, bool CONV>
 int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   constexpr int BN = 32 * WNT;
   constexpr bool GLDS = (NSPLIT == 1) && (sizeof(AT) == 2);
   p.zero_page = (const bf16*)ctx->zero_page;
   p.tiles_n = (p.N + BN - 1) / BN;
-  const int nk = (p.K + BK - 1) / BK;
-  {
-    p.tiles_m = (p.M + BM - 1) / BM;
-    const size_t lds = 2 * NSPLIT * (BM + BN) * 128;
-    void (*kern)(GemmP);
-    if constexpr (GLDS) kern = gemm_glds_kernel<WNT, YT, CONV>;
-    else kern = gemm_kernel<WNT, NSPLIT, AT, YT, CONV>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", lds, hipGetErrorString(e));
-      attr_set = true;
-    }
-    p.splits = choose_splits(p, p.tiles_n * p.tiles_m, batch);
-    if (p.splits > 1) {
-      p.slab = (float*)crg_scratch(ctx, (size_t)batch * p.splits * p.M * p.N * sizeof(float));
-      if (!p.slab) return crg_fail(ctx, -12, "gemm: out of scratch for %d split-K slabs", p.splits);
-    }
-    choose_xcd_partition(p, wk);
-    dim3 grid(p.tiles_n * p.tiles_m * p.splits, batch, 1);
-    constexpr int slot = !GLDS ? (CONV ? CRG_K_CONV_X3 : CRG_K_GEMM_X3)
-                               : (CONV ? (WNT == 5 ? CRG_K_CONV_W5 : WNT == 4 ? CRG_K_CONV_W4 : CRG_K_CONV_W1)
-                                       : (WNT == 5 ? CRG_K_GEMM_W5 : WNT == 4 ? CRG_K_GEMM_W4 : CRG_K_GEMM_W1));
-    crg_prof_scope ps(ctx, st, slot, wk.flops, wk.bytes);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
-    CRG_CHECK_LAUNCH(ctx, "gemm");
+  static const int force = getenv("CRG_GEMM_CFG") ? atoi(getenv("CRG_GEMM_CFG")) : 0;  // dev knob: 1 = A, 2 = B, 3 = C
+  // split-K first, on 128-row tiles: a long K is the cheapest source of blocks.  Only problems that stay below ~1 block per
+  // CU after that (short K) change the tile / wave configuration.
+  p.tiles_m = (p.M + 127) / 128;
+  p.splits = choose_splits(p, p.tiles_n * p.tiles_m, batch);
+  int cfg = 1;
+  if (GLDS && p.splits == 1) {
+    const long blocks = (long)p.tiles_m * p.tiles_n * batch;
+    if (blocks < 192) cfg = 3;
+    else if (blocks < 384) cfg = 2;
+  }
+  if (GLDS && force) cfg = force;
+  if (cfg == 3) {
+    p.tiles_m = (p.M + 63) / 64;
+    p.splits = force ? choose_splits(p, p.tiles_n * p.tiles_m, batch) : 1;
   }
   if (p.splits > 1) {
-    const long total = (long)p.M * (p.N >> 2);
-    const int rg = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    p.slab = (float*)crg_scratch(ctx, (size_t)batch * p.splits * p.M * p.N * sizeof(float));
+    if (!p.slab) return crg_fail(ctx, -12, "gemm: out of scratch for %d split-K slabs", p.splits);
+  }
+  choose_xcd_partition(p, wk);
+  int rc;
+  if constexpr (GLDS) {
+    if (cfg == 3) rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 4, 2, 2>(ctx, st, p, batch, wk);
+    else if (cfg == 2) rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 3, 4, 2>(ctx, st, p, batch, wk);
+    else rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 2, 4, 1>(ctx, st, p, batch, wk);
+  } else {
+    rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 2, 4, 1>(ctx, st, p, batch, wk);
+  }
+  if (rc) return rc;
+  if (p.splits > 1) {
+    const long total4 = (long)p.M * (p.N >> 2);
+    const int rg = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
     crg_prof_scope ps(ctx, st, CRG_K_SPLITK, (double)batch * p.splits * p.M * p.N,
                       (double)batch * p.M * p.N * (4.0 * p.splits + sizeof(YT)));
     hipLaunchKernelGGL(splitk_reduce_kernel<YT>, dim3(rg, batch), dim3(256), 0, st, p);

@@ -7,6 +7,7 @@ from cremage_amd import ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--kind", default="conv")
 ap.add_argument("--reps", type=int, default=50)
+ap.add_argument("--only", type=int, default=-1, help="run only the last N shapes")
 a = ap.parse_args()
 dev = "cuda:0"
 torch.manual_seed(0)
@@ -14,10 +15,12 @@ shapes = {
     "conv": [(8, 320, 64, 320), (8, 640, 32, 640), (8, 1280, 16, 1280), (8, 640, 64, 320), (8, 1280, 8, 1280), (8, 2560, 16, 1280),
              (8, 1280, 32, 640)],
     "gemm": [(32768, 320, 2880), (32768, 2560, 320), (8192, 640, 640), (8192, 5120, 640), (2048, 1280, 1280), (32768, 320, 320),
-             (2048, 10240, 1280), (2048, 1280, 5120), (512, 10240, 1280), (512, 1280, 5120), (8192, 640, 2560)],
+             (2048, 10240, 1280), (2048, 1280, 5120), (512, 10240, 1280), (512, 1280, 5120), (8192, 640, 2560),
+             (512, 1280, 1280), (512, 2560, 1280), (616, 1280, 768), (616, 640, 768), (2048, 2560, 1280), (8192, 1280, 640)],
+    "ksweep": [(2048, 1280, k) for k in (64, 128, 320, 640, 1280, 2560)] + [(8192, 640, k) for k in (64, 128, 320, 640, 1280, 2560)],
 }[a.kind]
-for sh in shapes:
-    if a.kind == "conv":
+for sh in (shapes[-a.only:] if a.only > 0 else shapes):
+    if a.kind == "conv":  # noqa
         n, ci, hw, co = sh
         x = torch.randn(n, ci, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         w = (torch.randn(co, ci, 3, 3, device=dev) * 0.02).to(torch.bfloat16)
