@@ -187,6 +187,83 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
+// ---- GroupNorm, small images (8x8 / 16x16 UNet levels): ONE launch, one block per (sample, group) ----
+// The group's HW x gs slab (gs % 8 == 0, at most 256 * VPT 16-byte vectors) is read once into registers, reduced
+// (shifted sums, wave shuffles + a fixed-order cross-wave sum: deterministic), normalised and written back.  Replaces the
+// two-pass stats/apply pair where that pair is pure launch + latency (a 1.3 MB tensor took ~15 us in two kernels).
+template <typename T, int VPT>
+__global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, int C, int HW,
+                                                       int groups, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, int silu, T* __restrict__ y) {
+  __shared__ float red[2][4];
+  const int n = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
+  const int gs = C / groups, wv = gs >> 3;
+  const int c_beg = g * gs;
+  const int C2 = C - C1;
+  const bool second = c_beg >= C1;  // C1 % gs == 0 is checked by the launcher: a group never straddles the two inputs
+  const T* base = second ? x2 + (long)n * HW * C2 + (c_beg - C1) : x + (long)n * HW * C1 + c_beg;
+  const int Cs = second ? C2 : C1;
+  const int total = HW * wv;
+  const float shift = (float)base[0];
+  crg_vec8<T> v[VPT];
+  int row[VPT], cv[VPT];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = t + 256 * k;
+    row[k] = i / wv;
+    cv[k] = i - row[k] * wv;
+    if (i < total) v[k].load(base + (long)row[k] * Cs + cv[k] * 8);
+  }
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    if (t + 256 * k < total) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[k].get(e) - shift;
+        s1 += d;
+        s2 += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  if ((t & 63) == 0) {
+    red[0][t >> 6] = s1;
+    red[1][t >> 6] = s2;
+  }
+  __syncthreads();
+  const double a = ((double)red[0][0] + (double)red[0][1]) + ((double)red[0][2] + (double)red[0][3]);
+  const double b = ((double)red[1][0] + (double)red[1][1]) + ((double)red[1][2] + (double)red[1][3]);
+  const double cnt = (double)HW * gs;
+  const double md = a / cnt;
+  double var = b / cnt - md * md;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)((double)shift + md);
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  T* yb = y + (long)n * HW * C + c_beg;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    if (t + 256 * k < total) {
+      const int c = c_beg + cv[k] * 8;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c), b1 = *reinterpret_cast<const f32x4*>(beta + c + 4);
+      crg_vec8<T> o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float ga = e < 4 ? g0[e] : g1[e - 4], be = e < 4 ? b0[e] : b1[e - 4];
+        float f = (v[k].get(e) - mean) * (rstd * ga) + be;
+        if (silu) f = crg_silu_f(f);
+        o.set(e, f);
+      }
+      o.store(yb + (long)row[k] * C + cv[k] * 8);
+    }
+  }
+}
+
 // ---- LayerNorm: one wave per row, row kept in registers (dim <= 64 lanes * 8 * LN_MAXC) ----------
 constexpr int LN_MAXC = 4;  // dim <= 2048
 template <typename T>
@@ -284,6 +361,30 @@ extern "C" int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const vo
   if (!x2) C1 = C;
   CRG_REQUIRE(ctx, C1 > 0 && C1 <= C && C1 % 8 == 0 && (C - C1) % 8 == 0, "groupnorm: concat split C1=%d of C=%d unsupported", C1, C);
   CRG_REQUIRE(ctx, dtype == CRG_BF16 || dtype == CRG_F32, "groupnorm: dtype %d unsupported", dtype);
+  // small images: single-launch path (one block per (sample, group), slab held in registers)
+  {
+    const int gs = C / groups;
+    const long vecs = (long)HW * (gs >> 3);
+    if (gs % 8 == 0 && C1 % gs == 0 && vecs <= 2560 && ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0) {
+      hipStream_t st = (hipStream_t)stream;
+      const double elems = (double)N * HW * C;
+      crg_prof_scope ps(ctx, st, CRG_K_GN_APPLY, 8.0 * elems, elems * crg_dtype_size(dtype) * 2);
+      dim3 grid(groups, N);
+#define CRG_GN_SMALL(TT, V) hipLaunchKernelGGL((gn_small_kernel<TT, V>), grid, dim3(256), 0, st, (const TT*)x, (const TT*)x2, C1, C, HW, groups, gamma, beta, eps, fuse_silu, (TT*)y)
+      if (dtype == CRG_BF16) {
+        if (vecs <= 512) CRG_GN_SMALL(bf16, 2);
+        else if (vecs <= 1280) CRG_GN_SMALL(bf16, 5);
+        else CRG_GN_SMALL(bf16, 10);
+      } else {
+        if (vecs <= 512) CRG_GN_SMALL(float, 2);
+        else if (vecs <= 1280) CRG_GN_SMALL(float, 5);
+        else CRG_GN_SMALL(float, 10);
+      }
+#undef CRG_GN_SMALL
+      CRG_CHECK_LAUNCH(ctx, "groupnorm(small)");
+      return 0;
+    }
+  }
   // rows per block: ~32 rows each, at most 256 chunks per sample (the apply prologue re-reduces them),
   // and at least ~512 blocks over the chip when the image is large enough
   int chunks = HW / 32;

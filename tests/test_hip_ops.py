@@ -177,7 +177,8 @@ def test_conv_small(dtype, ci, co, ks):
 
 # ------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("C,hw,eps", [(64, 8, 1e-5), (320, 12, 1e-5), (128, 33, 1e-6), (1280, 4, 1e-5), (32, 16, 1e-6)])
+@pytest.mark.parametrize("C,hw,eps", [(64, 8, 1e-5), (320, 12, 1e-5), (128, 33, 1e-6), (1280, 4, 1e-5), (32, 16, 1e-6),
+                                          (1280, 16, 1e-5), (2560, 16, 1e-5), (256, 32, 1e-6), (2560, 8, 1e-5)])  # last four: single-launch path
 @pytest.mark.parametrize("silu", [False, True])
 def test_group_norm(dtype, C, hw, eps, silu):
     from cremage_amd import ops
@@ -198,6 +199,12 @@ def test_group_norm_concat(dtype):
     ref = F.silu(F.group_norm(torch.cat([q(x1, dtype), q(x2, dtype)], 1), 32, g, b, 1e-5))
     got = ops.group_norm(nhwc(x1, dtype), g.to(_dev()), b.to(_dev()), 32, 1e-5, silu=True, x2=nhwc(x2, dtype))
     check(got, ref, dtype, "group_norm concat")
+    # single-launch path (group size 80, split on a group boundary)
+    x1, x2 = rnd(2, 1280, 8, 8, seed=57) - 2, rnd(2, 1280, 8, 8, seed=58) * 3 + 1
+    g, b = 1 + 0.1 * rnd(2560, seed=59), 0.1 * rnd(2560, seed=60)
+    ref = F.silu(F.group_norm(torch.cat([q(x1, dtype), q(x2, dtype)], 1), 32, g, b, 1e-5))
+    got = ops.group_norm(nhwc(x1, dtype), g.to(_dev()), b.to(_dev()), 32, 1e-5, silu=True, x2=nhwc(x2, dtype))
+    check(got, ref, dtype, "group_norm concat (small)")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
