@@ -202,9 +202,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][
   }
 }
 
-template <int WNT, int NSPLIT, typename AT, typename YT, bool CONV>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+// KG = 2 (the split-bf16 path): 8 waves; the second group of four multiplies the second 32-wide k-step of every k-tile and
+// every thread stages half as many rows.  That path fills the LDS with one block per CU, and with one wave per SIMD the
+// staging VALU work (fp32 -> hi/lo split, conv addressing: as many issue cycles as the MFMAs) ran strictly after the MFMAs;
+// two waves per SIMD overlap one wave's staging with the other's MFMAs.
+template <int WNT, int NSPLIT, typename AT, typename YT, bool CONV, int KG>
+__global__ __launch_bounds__(256 * KG) void gemm_kernel(GemmP p) {
   constexpr int BN = 32 * WNT;
+  constexpr int RS = 32 * KG;              // rows staged per pass by the block
+  constexpr int XL = BM / RS;              // A rows per thread
+  constexpr int WL = (BN + RS - 1) / RS;   // W rows per thread (last one guarded when RS does not divide BN)
   constexpr int XS_BYTES = BM * 128;
   constexpr int WS_BYTES = BN * 128;
   constexpr int STAGE_BYTES = NSPLIT * (XS_BYTES + WS_BYTES);
@@ -213,7 +220,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int kg = wave >> 2;
+  const int wm = (wave & 3) >> 1, wn = wave & 1;
 
   int tile_m, tile_n, sid;
   block_to_tile(p, tile_m, tile_n, sid);
@@ -226,15 +234,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   const bf16* Wlo = (NSPLIT == 2) ? p.w_lo + (long)bz * p.w_bs : nullptr;
 
   const int cc = t & 7;   // 16-byte chunk column inside the 64-wide k-tile
-  const int r0 = t >> 3;  // 0..31
+  const int r0 = t >> 3;  // 0..RS-1
 
   // ---- per-thread row descriptors (fixed for the whole K loop) ----
-  long xrow_off[4];   // linear: element offset of row start; conv: image index
-  int xh[4], xw[4];   // conv: top-left input coordinate (virtual = after upsample)
-  bool xok[4];
+  long xrow_off[XL];   // linear: element offset of row start; conv: image index
+  int xh[XL], xw[XL];  // conv: top-left input coordinate (virtual = after upsample)
+  bool xok[XL];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + r0 + 32 * i;
+  for (int i = 0; i < XL; ++i) {
+    const int m = m0 + r0 + RS * i;
     xok[i] = m < p.M;
     if (CONV) {
       const int hw = p.Ho * p.Wo;
@@ -250,18 +258,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       xh[i] = xw[i] = 0;
     }
   }
-  bool wok[WNT];
-  long wrow_off[WNT];
+  bool wok[WL];
+  long wrow_off[WL];
 #pragma unroll
-  for (int i = 0; i < WNT; ++i) {
-    const int n = n0 + r0 + 32 * i;
-    wok[i] = n < p.N;
+  for (int i = 0; i < WL; ++i) {
+    const int n = n0 + r0 + RS * i;
+    wok[i] = n < p.N && r0 + RS * i < BN;
     wrow_off[i] = (long)n * p.ldw;
   }
 
-  crg_vec8<AT> xr[4];
-  bf16x8 xr_lo[4];  // only when A is a pre-split weight (a_is_weight)
-  bf16x8 wr[WNT], wr_lo[WNT];
+  crg_vec8<AT> xr[XL];
+  bf16x8 xr_lo[XL];  // only when A is a pre-split weight (a_is_weight)
+  bf16x8 wr[WL], wr_lo[WL];
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
   auto load_tile = [&](int kt) {
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       const int Cs = second ? p.C2 : p.C1;
       const int cs = second ? c - p.C1 : c;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < XL; ++i) {
         const int hv = xh[i] + kh, wv = xw[i] + kw;
         const bool ok = kok && xok[i] && (unsigned)hv < (unsigned)Hv && (unsigned)wv < (unsigned)Wv;
         if (ok) {
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < XL; ++i) {
         if (kok && xok[i]) {
           xr[i].load(A + xrow_off[i] + kc);
           if (NSPLIT == 2 && sizeof(AT) == 2) xr_lo[i] = *reinterpret_cast<const bf16x8*>(A_lo + xrow_off[i] + kc);
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < WNT; ++i) {
+    for (int i = 0; i < WL; ++i) {
       if (kok && wok[i]) {
         wr[i] = *reinterpret_cast<const bf16x8*>(Wp + wrow_off[i] + kc);
         if (NSPLIT == 2) wr_lo[i] = *reinterpret_cast<const bf16x8*>(Wlo + wrow_off[i] + kc);
@@ -323,8 +331,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     char* xs = smem + stage * STAGE_BYTES;
     char* ws = xs + NSPLIT * XS_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = r0 + 32 * i;
+    for (int i = 0; i < XL; ++i) {
+      const int row = r0 + RS * i;
       const int off = lds_off(row, cc);
       if constexpr (sizeof(AT) == 4) {
         bf16x8 lo;
@@ -338,8 +346,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < WNT; ++i) {
-      const int row = r0 + 32 * i;
+    for (int i = 0; i < WL; ++i) {
+      const int row = r0 + RS * i;
+      if (RS * (WL - 1) + RS > BN && row >= BN) continue;  // guarded last pass
       const int off = lds_off(row, cc);
       *reinterpret_cast<bf16x8*>(ws + off) = wr[i];
       if (NSPLIT == 2) *reinterpret_cast<bf16x8*>(ws + WS_BYTES + off) = wr_lo[i];
@@ -367,7 +376,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     const char* xs = smem + (kt & 1) * STAGE_BYTES;
     const char* ws = xs + NSPLIT * XS_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int k2 = 0; k2 < 2 / KG; ++k2) {
+      const int ks = KG == 2 ? kg : k2;
       bf16x8 xf[4], xl[4], wf[WNT], wl[WNT];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -396,6 +406,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     __syncthreads();
   }
 
+  if constexpr (KG == 2) {
+    // fold the second k-group's partial tile into the first through the (now idle) staging buffers
+    static_assert(4 * WNT * 4 * 64 * 16 <= 2 * STAGE_BYTES, "reduction buffer must fit in the staging LDS");
+    f32x4* red = reinterpret_cast<f32x4*>(smem) + ((wave & 3) * WNT * 4) * 64 + lane;
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < WNT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[(i * 4 + j) * 64] = acc[i][j];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int i = 0; i < WNT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] += red[(i * 4 + j) * 64];
+  }
   const bf16x4 no_pre[WNT][4] = {};
   const f32x4 no_bias[WNT] = {};
   gemm_epilogue<WNT, YT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid, no_pre, false, no_bias, false);
@@ -744,7 +771,7 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   constexpr size_t lds = GLDS ? (size_t)STAGES * (32 * WMT + BN) * 128 + 1024 /* dummy-load target */ : (size_t)2 * NSPLIT * (BM + BN) * 128;
   void (*kern)(GemmP);
   if constexpr (GLDS) kern = gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG>;
-  else kern = gemm_kernel<WNT, NSPLIT, AT, YT, CONV>;
+  else kern = gemm_kernel<WNT, NSPLIT, AT, YT, CONV, NSPLIT>;  // split-bf16: 8 waves (two k-groups)
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -756,7 +783,7 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
                              : (CONV ? (WNT == 5 ? CRG_K_CONV_W5 : WNT == 4 ? CRG_K_CONV_W4 : CRG_K_CONV_W1)
                                      : (WNT == 5 ? CRG_K_GEMM_W5 : WNT == 4 ? CRG_K_GEMM_W4 : CRG_K_GEMM_W1));
   crg_prof_scope ps(ctx, st, slot, wk.flops, wk.bytes);
-  hipLaunchKernelGGL(kern, grid, dim3(GLDS ? 256 * KG : 256), lds, st, p);
+  hipLaunchKernelGGL(kern, grid, dim3(GLDS ? 256 * KG : 256 * NSPLIT), lds, st, p);
   CRG_CHECK_LAUNCH(ctx, "gemm");
   return 0;
 }
