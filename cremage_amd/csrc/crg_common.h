@@ -67,8 +67,23 @@ struct crg_prof_scope {
 static inline size_t crg_dtype_size(int dt) { return dt == CRG_F32 ? 4 : 2; }
 
 // ---- device helpers -------------------------------------------------------------------------
-__device__ __forceinline__ float crg_silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float crg_gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// x * sigmoid(x); v_rcp_f32 (1 ulp) instead of an IEEE division sequence
+__device__ __forceinline__ float crg_silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// erf-GELU (F.gelu default, attention.py:96 GEGLU).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, branch-free,
+// ~14 VALU ops): libm's erff is a ~40-instruction branchy sequence, which made the GEGLU epilogue cost twice the MFMA
+// time of the K=320 feed-forward GEMM.
+__device__ __forceinline__ float crg_erf_f(float x) {
+  const float ax = __builtin_fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+  float q = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  q = __builtin_fmaf(q, t, 1.421413741f);
+  q = __builtin_fmaf(q, t, -0.284496736f);
+  q = __builtin_fmaf(q, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  const float r = __builtin_fmaf(-q * t, e, 1.0f);
+  return __builtin_copysignf(r, x);
+}
+__device__ __forceinline__ float crg_gelu_erf_f(float x) { return 0.5f * x * (1.0f + crg_erf_f(x * 0.70710678118654752440f)); }
 
 template <typename T>
 struct crg_vec8;  // 8 consecutive elements of T, loaded/stored as one (bf16) or two (f32) 16-byte accesses
