@@ -15,7 +15,7 @@ template <typename T>
 __global__ __launch_bounds__(512) void gn_stats_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, int C, int HW,
                                                        int groups, int rows_per_chunk, float* __restrict__ part,
                                                        float* __restrict__ kbuf) {
-  __shared__ float s1[GN_MAX_GROUPS], s2[GN_MAX_GROUPS], shiftv[GN_MAX_GROUPS];
+  __shared__ float shiftv[GN_MAX_GROUPS];
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int tpr = C >> 3;                 // threads per row
   const int rpi = blockDim.x / tpr;       // rows per iteration
@@ -24,8 +24,6 @@ __global__ __launch_bounds__(512) void gn_stats_kernel(const T* __restrict__ x, 
   const int gs = C / groups;
   const int C2 = C - C1;
   if (t < groups) {
-    s1[t] = 0.f;
-    s2[t] = 0.f;
     const int c = t * gs;
     shiftv[t] = (c < C1) ? (float)x[(long)n * HW * C1 + c] : (float)x2[(long)n * HW * C2 + (c - C1)];
     if (chunk == 0) kbuf[n * groups + t] = shiftv[t];  // the apply pass must not re-read x (y may alias x)
@@ -73,28 +71,50 @@ __global__ __launch_bounds__(512) void gn_stats_kernel(const T* __restrict__ x, 
   }
   // Deterministic block reduction (no float atomics: results must not depend on arrival order): every lane parks its
   // 8 per-channel partials in LDS, then one lane per group adds its group's channels x row-lanes in a fixed order.
-  __shared__ float red[512 * 16];
+  __shared__ __attribute__((aligned(16))) float red[512 * 16];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     red[t * 16 + e] = (rl < rpi) ? a1[e] : 0.f;
     red[t * 16 + 8 + e] = (rl < rpi) ? a2[e] : 0.f;
   }
   __syncthreads();
+  // two short fixed-order phases instead of one long serial chain per group: (1) one thread per 8-channel column adds the
+  // row lanes, (2) one thread per group adds its channels
+  float c1[8], c2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) c1[e] = c2[e] = 0.f;
+  if (t < tpr) {
+    for (int r2 = 0; r2 < rpi; ++r2) {
+      const f32x4* q = reinterpret_cast<const f32x4*>(red + (r2 * tpr + t) * 16);
+      const f32x4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        c1[e] += q0[e];
+        c1[4 + e] += q1[e];
+        c2[e] += q2[e];
+        c2[4 + e] += q3[e];
+      }
+    }
+  }
+  __syncthreads();  // all row-lane partials consumed: the first tpr slots are rewritten with the column sums
+  if (t < tpr) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[t * 16 + e] = c1[e];
+      red[t * 16 + 8 + e] = c2[e];
+    }
+  }
+  __syncthreads();
   if (t < groups) {
     float b1 = 0.f, b2 = 0.f;
     for (int c = t * gs; c < (t + 1) * gs; ++c) {
-      const int cl = c >> 3, e = c & 7;
-      for (int r2 = 0; r2 < rpi; ++r2) {
-        const float* q = red + (r2 * tpr + cl) * 16;
-        b1 += q[e];
-        b2 += q[8 + e];
-      }
+      const float* q = red + (c >> 3) * 16 + (c & 7);
+      b1 += q[0];
+      b2 += q[8];
     }
-    s1[t] = b1;
-    s2[t] = b2;
     float* o = part + (((long)n * gridDim.x + chunk) * groups + t) * 2;
-    o[0] = s1[t];
-    o[1] = s2[t];
+    o[0] = b1;
+    o[1] = b2;
   }
 }
 
@@ -385,9 +405,9 @@ extern "C" int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const vo
       return 0;
     }
   }
-  // rows per block: ~32 rows each, at most 256 chunks per sample (the apply prologue re-reduces them),
+  // rows per block: ~64 rows each (the per-block reduction epilogue is the fixed cost), at most 256 chunks per sample (the apply prologue re-reduces them),
   // and at least ~512 blocks over the chip when the image is large enough
-  int chunks = HW / 32;
+  int chunks = HW / 64;
   if (chunks < 1) chunks = 1;
   if (chunks > 256) chunks = 256;
   while ((long)chunks * N < 512 && chunks * 8 <= HW && chunks < 256) chunks *= 2;
