@@ -56,7 +56,12 @@ DTYPES = [BF, torch.float32]
 
 # ------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(128, 160, 64), (300, 320, 328), (77, 128, 768), (8, 1280, 320), (1000, 200, 72), (130, 36, 40)])
+@pytest.mark.parametrize("M,N,K", [(128, 160, 64), (300, 320, 328), (77, 128, 768), (8, 1280, 320), (1000, 200, 72), (130, 36, 40),
+                                   # one shape per tile configuration of the LDS-DMA kernel (gemm_conv.hip `launch`):
+                                   (3000, 1280, 320),   # 192 tiles, short K          -> B (8 waves, in-block split-K)
+                                   (8200, 1280, 136),   # 520 tiles                   -> A (4 waves, 2 blocks per CU)
+                                   (2048, 640, 1280),   # 64 tiles, short K           -> C (64-row tiles)
+                                   (520, 320, 4096)])   # 10 tiles, long K            -> A + split-K
 def test_linear_shapes(dtype, M, N, K):
     from cremage_amd import ops
     x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
@@ -154,6 +159,17 @@ def test_conv2d(dtype, case):
     got = ops.conv2d(nhwc(x, dtype), w.to(_dev()), b.to(_dev()), x2=nhwc(x2, dtype) if x2 is not None else None,
                      cvec=cvec.to(_dev()) if cvec is not None else None, residual=nhwc(res, dtype) if res is not None else None, **kw)
     check(got, ref, dtype, "conv " + case)
+
+
+@pytest.mark.parametrize("N,C,Co,hw", [(2, 64, 320, 96), (4, 64, 320, 128), (1, 64, 640, 40)])
+def test_conv2d_tile_configs(N, C, Co, hw):
+    """bf16 3x3 convs sized to land on configurations B (288 blocks), A (1024 blocks) and C (130 tiles of 64 rows)."""
+    from cremage_amd import ops
+    x, w, b = rnd(N, C, hw, hw, seed=30), rnd(Co, C, 3, 3, seed=31, scale=(C * 9) ** -0.5), rnd(Co, seed=32)
+    res = rnd(N, Co, hw, hw, seed=33)
+    ref = conv_ref(x, w, b, BF) + q(res, BF)
+    got = ops.conv2d(nhwc(x, BF), w.to(_dev()), b.to(_dev()), residual=nhwc(res, BF))
+    check(got, ref, BF, f"conv cfg {N}x{C}x{hw}x{hw}->{Co}")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

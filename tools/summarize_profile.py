@@ -34,10 +34,10 @@ def slot_of(name):
     import re
     m = re.search(r"gemm_glds_kernel(?:<|ILi)(\d)", name)
     if m:
-        conv = ("Lb1E" in name) or ("bool _Accum" in name) or (", true>" in name)
+        conv = ("Lb1E" in name) or ("bool _Accum" in name) or bool(re.search(r", true[,>]", name))
         return ("conv_w" if conv else "gemm_w") + m.group(1)
     if "gemm_kernel" in name:
-        return "conv_x3" if (("Lb1E" in name) or (", true>" in name)) else "gemm_x3"
+        return "conv_x3" if (("Lb1E" in name) or re.search(r", true[,>]", name)) else "gemm_x3"
     for pat, slot in (("splitk_reduce", "splitk_reduce"), ("attn_kernel", "attention"), ("gn_stats", "gn_stats"), ("gn_apply", "gn_apply"),
                       ("layernorm_kernel", "layernorm"), ("softmax_rows", "softmax"), ("conv_small", "conv_small")):
         if pat in name:
