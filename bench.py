@@ -39,9 +39,11 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (C2: 4)")
     ap.add_argument("--sampler_steps", type=int, default=20)
     ap.add_argument("--sampler", default="euler_a")
-    ap.add_argument("--workload", default="sd15", choices=["sd15", "sdxl"],
-                    help="sd15 = BASELINE.json configs[1] (the headline metric, default); sdxl = configs[2] (SDXL 1024x1024 batch 2, "
-                         "30-step Euler EDM) as an extra, separately labelled measurement")
+    ap.add_argument("--workload", default="sd15", choices=["sd15", "sdxl", "img2img", "controlnet"],
+                    help="sd15 = BASELINE.json configs[1] (the headline metric, default).  Extra, separately labelled measurements: "
+                         "sdxl = configs[2] (SDXL 1024x1024 batch 2, 30-step Euler EDM); img2img = configs[3]'s per-GPU unit (SD1.5 "
+                         "img2img 768x768, 2 images per GPU, DDIM 20 steps strength 0.75, VAE encode + decode); controlnet = "
+                         "configs[1] with a ControlNet attached (SURVEY 8f row 1)")
     ap.add_argument("--no-graph", action="store_true", help="launch the UNet eagerly instead of replaying a captured hipGraph "
                                                             "(measured A/B on MI355X: replay is 0-3 % faster and steadier)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -54,6 +56,8 @@ def main():
 
     if a.workload == "sdxl":
         return main_sdxl(a)
+    if a.workload in ("img2img", "controlnet"):
+        return main_extra(a)
     rank, world, local = D.init_from_env()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
@@ -192,6 +196,86 @@ def roofline_of(kernels):
             "avg_launch_us": round(1e3 * k["ms"] / n, 2), "algorithmic_gflop_per_launch": round(k["flops"] / n / 1e9, 3),
             "algorithmic_mbytes_per_launch": round(k["bytes"] / n / 1e6, 3),
             "kernels_ms_per_step": {name: round(v["ms"], 3) for name, v in kernels.items() if v["launches"]}}
+
+
+def main_extra(a):
+    """Extra SD1.5 workloads on the same path (same sharding and timing protocol as the headline run)."""
+    from cremage_amd import dist as D
+    from cremage_amd import ops, pipeline as P
+    from cremage_amd.synth import synth_input
+    rank, world, local = D.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    t0 = time.time()
+    if a.workload == "controlnet":
+        ldm = P.build_synthetic_control_ldm(device=dev)
+        b, hw = a.batch, 512
+    else:
+        ldm = P.build_synthetic_ldm(device=dev)
+        b, hw = (2 if a.batch == 4 else a.batch), 768
+    D.broadcast_module_(ldm, src=0)  # every rank filled the same name-keyed weights; the broadcast makes rank 0 authoritative
+    t_build = time.time() - t0
+    L = hw // 8
+    first = rank * b
+    c = torch.stack([synth_input(f"bench.c{first + i}", (77, 768), 7) for i in range(b)]).to(dev)
+    uc = synth_input("bench.uc", (1, 77, 768), 7).expand(b, -1, -1).contiguous().to(dev)
+    gens = [torch.Generator(device=dev).manual_seed(D.image_seed(42, first + i)) for i in range(b)]
+    rnd = lambda shape: torch.stack([torch.randn(shape, generator=g, device=dev) for g in gens])
+    if a.workload == "controlnet":
+        hint = torch.stack([synth_input(f"bench.hint{first + i}", (3, hw, hw), 44, 0.5) for i in range(b)]).clamp(-1, 1).mul(0.5).add(0.5).to(dev)
+
+        def step():
+            images, _ = P.txt2img(ldm, c, uc, steps=a.sampler_steps, sampler=a.sampler, cfg_scale=7.5, height=hw, width=hw,
+                                  x0=rnd((4, L, L)), noise_sampler=lambda s, sn: rnd((4, L, L)), hint=hint)
+            return D.all_gather_batch(images)
+        # ControlNet = encoder half + middle of the UNet + hint encoder: FLOPs counted by the profiler below, not assumed
+        metric = "images/sec SD1.5 512x512 20-step Euler ancestral + ControlNet (txt2img, CFG 7.5, incl. VAE decode)"
+        workload = ("SD1.5 txt2img 512x512 with a ControlNet (cldm_v15.yaml), batch 4 per GPU, 20-step Euler ancestral, bf16 UNet + "
+                    "ControlNet (B=8 with CFG), fp32-class VAE decode, synthetic weights / conditioning / hint")
+        flops_per_image = None
+    else:
+        img = torch.stack([synth_input(f"bench.img{first + i}", (3, hw, hw), 44, 0.5) for i in range(b)]).clamp(-1, 1).to(dev)
+
+        def step():
+            images, _ = P.img2img(ldm, img, c, uc, steps=a.sampler_steps, strength=0.75, cfg_scale=7.5, enc_noise=rnd((4, L, L)),
+                                  fwd_noise=rnd((4, L, L)))
+            return D.all_gather_batch(images)
+        metric = "images/sec SD1.5 img2img 768x768 20-step DDIM strength 0.75 (VAE encode + 15 UNet steps x CFG + VAE decode)"
+        workload = ("SD1.5 img2img 768x768 (BASELINE.json configs[3] per-GPU unit), 2 images per GPU, DDIM 20 steps, strength 0.75 -> "
+                    "t_enc 15, bf16 UNet (B=4 with CFG, L=96), fp32-class VAE encode + decode, synthetic weights / inputs")
+        flops_per_image = 2609.1e9 + 30 * 2148.1e9 + 5754.3e9  # SURVEY 8d: enc 768^2 + 15 x 2 x UNet(L=96) + dec(L=96)
+    for _ in range(a.warmup):
+        step()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    assert out.shape == (world * b, 3, hw, hw) and torch.isfinite(out).all()
+    value = world * b * a.steps / dt
+    res = {"metric": metric, "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+           "data": "synthetic", "config": {"workload": workload, "images_per_gpu_per_step": b, "sampler_steps": a.sampler_steps},
+           "model_build_s": round(t_build, 1)}
+    if rank == 0 and not a.no_roofline:
+        with ops.profile(local) as prof:
+            step()
+        fam = prof.result
+        res["roofline"] = roofline_of(prof.kernels)
+        res["roofline"]["traffic"] = res["roofline"]["traffic_source"] = None  # the committed PMC passes are of the headline workload
+        res["kernel_families_ms_per_step"] = {k: round(v["ms"], 3) for k, v in fam.items() if v["launches"]}
+        total_flops = sum(v["flops"] for k, v in fam.items() if k in ("gemm", "conv", "attention", "conv_small"))
+        res["algorithmic_gflop_per_image"] = round((flops_per_image if flops_per_image else total_flops / b) / 1e9, 1)
+        res["whole_path_mfma_frac"] = round(value / world * res["algorithmic_gflop_per_image"] * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 def main_sdxl(a):

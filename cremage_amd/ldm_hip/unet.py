@@ -299,10 +299,9 @@ class UNetModel(nn.Module):
             return torch.bfloat16
         return torch.float32
 
-    def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
-        """x [N, C, H, W] (any float dtype, NCHW) , timesteps [N] (may be fractional), context [N, T, D]
-        -> eps [N, C_out, H, W] in x.dtype (openaimodel.py:780-816)."""
-        assert y is None, "must specify y if and only if the model is class-conditional"
+    def _prologue(self, timesteps, context):
+        """timestep embedding MLP (openaimodel.py:793-796) + the per-step batched ResBlock projections + one cast of the
+        context per context tensor -> (compute dtype, emb, context)."""
         cdt = self.resolve_compute_dtype()
         t_emb = timestep_embedding(timesteps, self.model_channels, dtype=cdt)
         emb = self.time_embed[0](t_emb, act="silu")
@@ -315,6 +314,19 @@ class UNetModel(nn.Module):
             if c is None or c[0] is not context or c[1] != context._version or c[2].dtype != cdt:
                 self._ctx_cast = c = (context, context._version, context.to(cdt))
             context = c[2]
+        return cdt, emb, context
+
+    def _epilogue(self, h, x):
+        """out = conv3x3(SiLU(GN32(h))) (openaimodel.py:752-756,816), back to NCHW in x.dtype (:810)."""
+        h = self.out[0](h, silu=True)
+        h = self.out[2](h)
+        return ops.nhwc_to_nchw(h, x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32).to(x.dtype)
+
+    def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
+        """x [N, C, H, W] (any float dtype, NCHW) , timesteps [N] (may be fractional), context [N, T, D]
+        -> eps [N, C_out, H, W] in x.dtype (openaimodel.py:780-816)."""
+        assert y is None, "must specify y if and only if the model is class-conditional"
+        cdt, emb, context = self._prologue(timesteps, context)
         hs = []
         h = ops.nchw_to_nhwc(x, cdt)
         for module in self.input_blocks:
@@ -323,6 +335,4 @@ class UNetModel(nn.Module):
         h = self.middle_block(h, emb, context)
         for module in self.output_blocks:
             h = module((h, hs.pop()), emb, context)
-        h = self.out[0](h, silu=True)
-        h = self.out[2](h)
-        return ops.nhwc_to_nchw(h, x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32).to(x.dtype)
+        return self._epilogue(h, x)

@@ -47,6 +47,23 @@ def build_synthetic_ldm(unet_cfg=None, vae_dd=None, device="cuda", unet_dtype=to
     return ldm.to(device).eval()
 
 
+def build_synthetic_control_ldm(unet_cfg=None, vae_dd=None, device="cuda", unet_dtype=torch.bfloat16, vae_dtype=torch.float32, seed: int = 1234):
+    """ControlLDM (cldm.py:345-393, cldm_v15.yaml) with name-keyed synthetic weights: ControlledUnetModel + ControlNet + VAE."""
+    from .cldm_hip import ControlLDM, ControlledUnetModel, ControlNet
+    cfg = unet_cfg or SD15_UNET
+    unet = ControlledUnetModel(**cfg)
+    cnet = ControlNet(hint_channels=3, **{k: v for k, v in cfg.items() if k != "out_channels"})
+    vae = AutoencoderKL(vae_dd or SD15_VAE_DD, None, 4)
+    synth_fill_(unet, seed, prefix="unet.")
+    synth_fill_(cnet, seed, prefix="cn.")
+    synth_fill_(vae, seed, prefix="vae.")
+    ldm = ControlLDM(cnet, "hint", False, unet, vae)
+    ldm.model.to(unet_dtype)
+    ldm.control_model.to(unet_dtype)
+    ldm.first_stage_model.to(vae_dtype)
+    return ldm.to(device).eval()
+
+
 @torch.no_grad()
 def decode_images(ldm: LatentDiffusion, samples: torch.Tensor, batch_decode: bool = True) -> torch.Tensor:
     """latents [b,4,L,L] -> images [b,3,8L,8L] fp32 in [0,1] (image_generator.py:1007-1015).  The reference
@@ -62,9 +79,14 @@ def decode_images(ldm: LatentDiffusion, samples: torch.Tensor, batch_decode: boo
 @torch.no_grad()
 def txt2img(ldm: LatentDiffusion, c: torch.Tensor, uc: Optional[torch.Tensor], *, steps: int = 20, sampler: str = "euler_a",
             cfg_scale: float = 7.5, height: int = 512, width: int = 512, x0: Optional[torch.Tensor] = None,
-            noise_sampler: Optional[Callable] = None, decode: bool = True):
-    """Returns (images or None, final latents)."""
+            noise_sampler: Optional[Callable] = None, decode: bool = True, hint: Optional[torch.Tensor] = None):
+    """Returns (images or None, final latents).  `hint` ([b,3,H,W] in [0,1], ControlLDM only): the ControlNet control image;
+    conditioning becomes {"c_crossattn": [c], "c_concat": [hint]} for both the positive and the negative prompt
+    (image_generator.py:795-808)."""
     b = c.shape[0]
+    if hint is not None:
+        c = {"c_crossattn": [c], "c_concat": [hint]}
+        uc = {"c_crossattn": [uc], "c_concat": [hint]} if uc is not None else None
     shape = [4, height // 8, width // 8]
     smp = SAMPLERS[sampler](ldm)
     smp.noise_sampler = noise_sampler

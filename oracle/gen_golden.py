@@ -510,6 +510,72 @@ def g_controlnet_hook():
     save("hook_controlnet", dict(cfg=TINY_UNET, B=B, L=L, seed=SEED, prefix="unet.", shapes=shapes), t=t, y=y, y_mid=y_mid)
 
 
+
+def g_controlnet():
+    """The reference's ControlNet (cldm.py:73-342) feeding its ControlledUnetModel (:28-70) exactly as
+    ControlLDM.apply_model does (:374-393, control_scales all 1.0 and a non-trivial set), tiny and SD-shaped small."""
+    from cldm.cldm import ControlledUnetModel, ControlNet
+    for name, cfg, B, L, tvals in [("controlnet_tiny", TINY_UNET, 2, 16, [250.0, 600.5]), ("controlnet_small_sd", SMALL_SD_UNET, 2, 16, [40.0, 905.5])]:
+        ccfg = {k: v for k, v in cfg.items() if k != "out_channels"}
+        cn = ControlNet(hint_channels=3, **ccfg)
+        un = ControlledUnetModel(**cfg)
+        synth_fill_(cn, SEED, prefix="cn.")
+        synth_fill_(un, SEED, prefix="unet.")
+        x = synth_input("cnet.x", (B, 4, L, L), SEED)
+        hint = synth_input("cnet.hint", (B, 3, 8 * L, 8 * L), SEED, 0.5).clamp(-1, 1) * 0.5 + 0.5
+        ctx = synth_input("cnet.ctx", (B, 77, cfg["context_dim"]), SEED)
+        t = torch.tensor(tvals)
+        n_ctrl = len(cn.input_blocks) + 1
+        scales = [0.6 + 0.05 * i for i in range(n_ctrl)]
+        orig_half = torch.Tensor.half
+        torch.Tensor.half = lambda self, *a, **k: self  # cldm.py:54-55,67-68,322-323 cast on non-'cuda' devices
+        try:
+            with fp32_forward():
+                control = cn(x=x, hint=hint, timesteps=t, context=ctx)
+                eps = un(x=x, timesteps=t, context=ctx, control=[c.clone() for c in control], only_mid_control=False)
+                eps_scaled = un(x=x, timesteps=t, context=ctx, control=[c * s for c, s in zip(control, scales)], only_mid_control=False)
+                eps_mid = un(x=x, timesteps=t, context=ctx, control=[c.clone() for c in control], only_mid_control=True)
+        finally:
+            torch.Tensor.half = orig_half
+        assert len(control) == n_ctrl
+        arrays = {f"control{i}": c for i, c in enumerate(control)}
+        # parameter-name contract of the full-size ControlNet (cldm_v15.yaml control_stage_config), built on the meta device
+        import hashlib
+        with torch.device("meta"):
+            full = ControlNet(hint_channels=3, **{k: v for k, v in SD15_UNET.items() if k != "out_channels"})
+        items = sorted(f"{k}:{tuple(v.shape)}" for k, v in full.state_dict().items())
+        save(name, dict(cfg=cfg, B=B, L=L, seed=SEED, cn_prefix="cn.", unet_prefix="unet.", n_control=n_ctrl, scales=scales,
+                        cn_sd15_sha1=hashlib.sha1("\n".join(items).encode()).hexdigest(), cn_sd15_n=len(items)),
+             t=t, eps=eps, eps_scaled=eps_scaled, eps_mid=eps_mid, **arrays)
+
+
+def g_controlnet_sd15_full():
+    """Full-size ControlNet (361 M params, cldm_v15.yaml) + ControlledUnetModel at B=2 (one image x CFG), L=64, 512x512 hint:
+    eps in full, every control tensor sub-sampled (stride 4 spatially) to keep the fixture small."""
+    from cldm.cldm import ControlledUnetModel, ControlNet
+    cfg = SD15_UNET
+    cn = ControlNet(hint_channels=3, **{k: v for k, v in cfg.items() if k != "out_channels"})
+    un = ControlledUnetModel(**cfg)
+    synth_fill_(cn, SEED, prefix="cn.")
+    synth_fill_(un, SEED, prefix="unet.")
+    B, L = 2, 64
+    x = synth_input("cnet.x", (B, 4, L, L), SEED)
+    hint = synth_input("cnet.hint", (B, 3, 8 * L, 8 * L), SEED, 0.5).clamp(-1, 1) * 0.5 + 0.5
+    ctx = synth_input("cnet.ctx", (B, 77, cfg["context_dim"]), SEED)
+    t = torch.tensor([801.0, 801.0])
+    orig_half = torch.Tensor.half
+    torch.Tensor.half = lambda self, *a, **k: self
+    try:
+        with fp32_forward():
+            control = cn(x=x, hint=hint, timesteps=t, context=ctx)
+            eps = un(x=x, timesteps=t, context=ctx, control=[c.clone() for c in control], only_mid_control=False)
+    finally:
+        torch.Tensor.half = orig_half
+    arrays = {f"control{i}_sub": c[:, :, ::4, ::4].contiguous() for i, c in enumerate(control)}
+    save("controlnet_sd15_full", dict(cfg=cfg, B=B, L=L, seed=SEED, cn_prefix="cn.", unet_prefix="unet.", n_control=len(control),
+                                      n_params=sum(p.numel() for p in cn.parameters())), t=t, eps=eps, **arrays)
+
+
 # ---------------------------------------------------------------------------- SDXL (sgm)
 
 TINY_SGM_UNET = dict(adm_in_channels=96, num_classes="sequential", use_checkpoint=False, in_channels=4, out_channels=4,
@@ -597,9 +663,9 @@ def g_sgm_trajectory():
 CASES = dict(alphas_doc=g_alphas_doc, param_contract=g_param_contract, groupnorm=g_groupnorm, timestep_embedding=g_timestep_embedding, resblock=g_resblock, updown=g_updown,
              attention=g_attention, transformer=g_transformer, unet_tiny=g_unet_tiny, unet_small_sd=g_unet_small_sd,
              vae_blocks=g_vae_blocks, vae_tiny=g_vae_tiny, schedules=g_schedules, trajectories=g_trajectories)
-CASES.update(controlnet_hook=g_controlnet_hook)
+CASES.update(controlnet_hook=g_controlnet_hook, controlnet=g_controlnet)
 CASES.update(sgm_unet_tiny=g_sgm_unet_tiny, sgm_unet_small=g_sgm_unet_small, sgm_trajectory=g_sgm_trajectory)
-FULL = dict(unet_sd15_full=g_unet_sd15_full, vae_sd15_full=g_vae_sd15_full, sgm_unet_full=g_sgm_unet_full)
+FULL = dict(controlnet_sd15_full=g_controlnet_sd15_full, unet_sd15_full=g_unet_sd15_full, vae_sd15_full=g_vae_sd15_full, sgm_unet_full=g_sgm_unet_full)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

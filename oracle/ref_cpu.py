@@ -309,6 +309,72 @@ def unet_forward(sd: SD, cfg: dict, x, timesteps, context, control: Optional[Seq
     return conv2d(silu(h), sd, "out.2", padding=1)
 
 
+def controlnet_forward(sd: SD, cfg: dict, x, hint, timesteps, context, **kw):
+    """ControlNet.forward modules/cldm/cldm.py:319-342 (ctor :80-317): the UNet's encoder half + middle block with
+    its own weights.  guided_hint = input_hint_block(hint) (:178-194: 8 convs 3x3, SiLU between, strides
+    1,1,2,1,2,1,2,1, hint_channels -> 16,16,32,32,96,96,256 -> model_channels) is added to the output of the first
+    input block only (:329-333); every input block's output goes through its own 1x1 `zero_convs[i]` (:335,
+    make_zero_conv :316-317) and the middle block's through `middle_block_out` (:337-338).  Returns the list
+    [zero_conv_0(h_0), ..., zero_conv_11(h_11), middle_block_out(h_mid)] (13 tensors for the SD1.5 layout)."""
+    inp, mid, _ = unet_layout(cfg)
+    depth = cfg.get("transformer_depth", 1)
+    t_emb = timestep_embedding(timesteps, cfg["model_channels"]).to(x.dtype)
+    emb = linear(silu(linear(t_emb, sd, "time_embed.0")), sd, "time_embed.2")
+    g = hint
+    strides = [1, 1, 2, 1, 2, 1, 2, 1]
+    for j, st in enumerate(strides):
+        g = conv2d(g, sd, f"input_hint_block.{2 * j}", stride=st, padding=1)
+        if j + 1 < len(strides):
+            g = silu(g)
+    outs = []
+    h = x
+    for i, layers in enumerate(inp):
+        h = _run_block(h, emb, context, sd, f"input_blocks.{i}", layers, depth, **kw)
+        if i == 0:
+            h = h + g
+        outs.append(conv2d(h, sd, f"zero_convs.{i}.0"))
+    h = _run_block(h, emb, context, sd, "middle_block", mid, depth, **kw)
+    outs.append(conv2d(h, sd, "middle_block_out.0"))
+    return outs
+
+
+def control_ldm_apply_model(unet_sd: SD, cn_sd: SD, cfg: dict, x, t, c_crossattn, c_concat, control_scales=None,
+                            only_mid_control: bool = False, **kw):
+    """ControlLDM.apply_model cldm.py:374-393: control = control_model(x, hint=cat(c_concat,1), t, ctx); each scaled by
+    control_scales[i] (:388, default 1.0 x 13 :360); eps = ControlledUnetModel(x, t, ctx, control, only_mid_control)
+    (:28-70: `h += control.pop()` after the middle block; `hs.pop() + control.pop()` for every skip unless
+    only_mid_control).  With c_concat None the plain UNet runs (:384-385)."""
+    ctx = torch.cat(list(c_crossattn), 1)
+    if c_concat is None:
+        return unet_forward(unet_sd, cfg, x, t, ctx, **kw)
+    control = controlnet_forward(cn_sd, cfg, x, torch.cat(list(c_concat), 1), t, ctx, **kw)
+    if control_scales is not None:
+        control = [c * s for c, s in zip(control, control_scales)]
+    if only_mid_control:
+        control = control[-1:]
+        return _unet_forward_mid_only(unet_sd, cfg, x, t, ctx, control[0], **kw)
+    return unet_forward(unet_sd, cfg, x, t, ctx, control=control, **kw)
+
+
+def _unet_forward_mid_only(sd: SD, cfg: dict, x, timesteps, context, mid_control, **kw):
+    """ControlledUnetModel.forward with only_mid_control=True (cldm.py:57-63): only the middle residual is added."""
+    inp, mid, out = unet_layout(cfg)
+    depth = cfg.get("transformer_depth", 1)
+    t_emb = timestep_embedding(timesteps, cfg["model_channels"]).to(x.dtype)
+    emb = linear(silu(linear(t_emb, sd, "time_embed.0")), sd, "time_embed.2")
+    hs = []
+    h = x
+    for i, layers in enumerate(inp):
+        h = _run_block(h, emb, context, sd, f"input_blocks.{i}", layers, depth, **kw)
+        hs.append(h)
+    h = _run_block(h, emb, context, sd, "middle_block", mid, depth, **kw) + mid_control
+    for i, layers in enumerate(out):
+        h = torch.cat([h, hs.pop()], dim=1)
+        h = _run_block(h, emb, context, sd, f"output_blocks.{i}", layers, depth, **kw)
+    h = group_norm(h, sd["out.0.weight"].to(h.dtype), sd["out.0.bias"].to(h.dtype), 32, 1e-5)
+    return conv2d(silu(h), sd, "out.2", padding=1)
+
+
 # ----------------------------------------------------------------------------
 # VAE (modules/ldm/modules/diffusionmodules/model.py, modules/ldm/models/autoencoder.py)
 # ----------------------------------------------------------------------------

@@ -382,6 +382,68 @@ def test_controlnet_hook_attaches(dtype):
     close(y_mid, g["y_mid"], TOL_NET[dtype], "controlnet hook (mid only)")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, BF])
+@pytest.mark.parametrize("name", ["controlnet_tiny", "controlnet_small_sd"])
+def test_controlnet_fast_path(dtype, name):
+    """the HIP ControlNet (cldm.py:73-342) and ControlLDM.apply_model (:374-393) against the reference's
+    own modules: the control tensors, eps with unit / non-trivial control_scales, only_mid_control; and the hint cache."""
+    from cremage_amd.cldm_hip import ControlLDM, ControlledUnetModel, ControlNet
+    from cremage_amd.ldm_hip.vae import AutoencoderKL
+    meta, g = load_golden(name)
+    cfg = meta["cfg"]
+    cn = ControlNet(hint_channels=3, **{k: v for k, v in cfg.items() if k != "out_channels"})
+    un = ControlledUnetModel(**cfg)
+    synth_fill_(cn, meta["seed"], prefix=meta["cn_prefix"])
+    synth_fill_(un, meta["seed"], prefix=meta["unet_prefix"])
+    vae = AutoencoderKL(dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2], num_res_blocks=1,
+                             attn_resolutions=[], dropout=0.0), None, 4)
+    ldm = ControlLDM(cn, "hint", False, un, vae)
+    ldm = ldm.to(dtype).to(DEV).eval()
+    B, L, seed = meta["B"], meta["L"], meta["seed"]
+    x = synth_input("cnet.x", (B, 4, L, L), seed).to(DEV)
+    hint = (synth_input("cnet.hint", (B, 3, 8 * L, 8 * L), seed, 0.5).clamp(-1, 1) * 0.5 + 0.5).to(DEV)
+    ctx = synth_input("cnet.ctx", (B, 77, cfg["context_dim"]), seed).to(DEV)
+    t = g["t"].to(DEV)
+    with torch.no_grad():
+        control = ldm.control_model(x=x, hint=hint, timesteps=t, context=ctx)
+        assert len(control) == meta["n_control"]
+        for i, c in enumerate(control):
+            close(c, g[f"control{i}"], TOL_NET[dtype], f"control{i}")
+        cond = {"c_crossattn": [ctx], "c_concat": [hint]}
+        close(ldm.apply_model(x, t, cond), g["eps"], TOL_NET[dtype], "eps")
+        assert ldm.control_model._hint_cache is not None and ldm.control_model._hint_cache[0][0] is hint  # second call: cached
+        ldm.control_scales = list(meta["scales"])
+        close(ldm.apply_model(x, t, cond), g["eps_scaled"], TOL_NET[dtype], "eps (control_scales)")
+        ldm.control_scales = [1.0] * meta["n_control"]
+        ldm.only_mid_control = True
+        close(ldm.apply_model(x, t, cond), g["eps_mid"], TOL_NET[dtype], "eps (only_mid_control)")
+        # a changed hint image must not hit the cache
+        hint.mul_(0.5)
+        g2 = ldm.control_model.guided_hint(hint, control[0].dtype)
+        hint.mul_(2.0)
+        g1 = ldm.control_model.guided_hint(hint, control[0].dtype)
+        assert rel_l2(g2.float().cpu(), g1.float().cpu()) > 1e-2
+
+
+def test_controlnet_sd15_full():
+    """Full-size ControlNet (cldm_v15.yaml: 361 M params) + SD1.5 UNet, bf16, B=2, L=64, 512x512 hint vs the reference."""
+    from cremage_amd import pipeline as P
+    meta, g = load_golden("controlnet_sd15_full")
+    ldm = P.build_synthetic_control_ldm(device=DEV, seed=meta["seed"])
+    assert sum(p.numel() for p in ldm.control_model.parameters()) == meta["n_params"]
+    B, L, seed = meta["B"], meta["L"], meta["seed"]
+    x = synth_input("cnet.x", (B, 4, L, L), seed).to(DEV)
+    hint = (synth_input("cnet.hint", (B, 3, 8 * L, 8 * L), seed, 0.5).clamp(-1, 1) * 0.5 + 0.5).to(DEV)
+    ctx = synth_input("cnet.ctx", (B, 77, 768), seed).to(DEV)
+    t = g["t"].to(DEV)
+    with torch.no_grad():
+        control = ldm.control_model(x=x, hint=hint, timesteps=t, context=ctx)
+        for i, c in enumerate(control):
+            close(c[:, :, ::4, ::4], g[f"control{i}_sub"], TOL_NET[BF], f"control{i}")
+        eps = ldm.apply_model(x, t, {"c_crossattn": [ctx], "c_concat": [hint]})
+    close(eps, g["eps"], TOL_NET[BF], "eps")
+
+
 def test_c4_unit_img2img_768_properties():
     """BASELINE.json configs[3]'s per-GPU unit at full size (SD1.5 img2img 768x768, 2 images, DDIM, strength 0.75 ->
     t_enc = 15 of 20 steps, VAE encode + decode) through size-independent properties: determinism (bitwise), and

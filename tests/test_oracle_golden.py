@@ -258,3 +258,39 @@ def test_controlnet_hook_oracle():
     control = [synth_input(f"cn.control{i}", (B,) + tuple(s), seed, 0.3) for i, s in enumerate(meta["shapes"])]
     y = R.unet_forward(sd, cfg, x, g["t"], ctx, control=control)
     assert max_abs(y, g["y"]) < 2e-4
+
+
+@pytest.mark.parametrize("name", ["controlnet_tiny", "controlnet_small_sd"])
+def test_controlnet_oracle(name):
+    """oracle restatement of ControlNet.forward (cldm.py:319-342) + ControlLDM.apply_model (:374-393) against the
+    reference's own modules (13 control tensors and eps with unit scales, non-trivial scales, only_mid_control)"""
+    meta, g = load_golden(name)
+    from cremage_amd.cldm_hip import ControlledUnetModel, ControlNet
+    cfg = meta["cfg"]
+    ccfg = {k: v for k, v in cfg.items() if k != "out_channels"}
+    cn_sd = synth_state_dict(ControlNet(hint_channels=3, **ccfg), meta["seed"], meta["cn_prefix"])
+    un_sd = synth_state_dict(ControlledUnetModel(**cfg), meta["seed"], meta["unet_prefix"])
+    B, L, seed = meta["B"], meta["L"], meta["seed"]
+    x = synth_input("cnet.x", (B, 4, L, L), seed)
+    hint = synth_input("cnet.hint", (B, 3, 8 * L, 8 * L), seed, 0.5).clamp(-1, 1) * 0.5 + 0.5
+    ctx = synth_input("cnet.ctx", (B, 77, cfg["context_dim"]), seed)
+    control = R.controlnet_forward(cn_sd, cfg, x, hint, g["t"], ctx)
+    assert len(control) == meta["n_control"]
+    for i, c in enumerate(control):
+        assert max_abs(c, g[f"control{i}"]) < 2e-4, i
+    for key, kw in [("eps", {}), ("eps_scaled", dict(control_scales=meta["scales"])), ("eps_mid", dict(only_mid_control=True))]:
+        eps = R.control_ldm_apply_model(un_sd, cn_sd, cfg, x, g["t"], [ctx], [hint], **kw)
+        assert max_abs(eps, g[key]) < 5e-4, key
+
+
+def test_controlnet_param_contract():
+    """the HIP ControlNet exposes exactly the reference's parameter names/shapes at the cldm_v15.yaml size"""
+    import hashlib
+    meta, _ = load_golden("controlnet_tiny")
+    from cremage_amd.cldm_hip import ControlNet
+    from cremage_amd.pipeline import SD15_UNET
+    with torch.device("meta"):
+        m = ControlNet(hint_channels=3, **{k: v for k, v in SD15_UNET.items() if k != "out_channels"})
+    items = sorted(f"{k}:{tuple(v.shape)}" for k, v in m.state_dict().items())
+    assert len(items) == meta["cn_sd15_n"]
+    assert hashlib.sha1("\n".join(items).encode()).hexdigest() == meta["cn_sd15_sha1"]
