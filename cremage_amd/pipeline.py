@@ -149,3 +149,15 @@ def txt2img_sdxl(eng, c: dict, uc: dict, *, steps: int = 30, cfg_scale: float = 
         return None, samples
     x = eng.decode_first_stage(samples)
     return ops.affine_cast(x, 0.5, 0.5, torch.float32, 0.0, 1.0), samples
+
+
+@torch.no_grad()
+def img2img_sdxl(eng, init_image: torch.Tensor, c: dict, uc: dict, *, steps: int = 30, strength: float = 0.3, cfg_scale: float = 5.0,
+                 enc_noise: Optional[torch.Tensor] = None, fwd_noise: Optional[torch.Tensor] = None, decode: bool = True):
+    """run_img2img -> do_img2img (sdxl_image_generator_utils.py:775-1025); with strength 0.3 on a face crop this is the second
+    pass of the auto-face-fix (modules/sdxl/face_img2img... -> the same do_img2img).  init_image [b,3,H,W] in [-1,1]."""
+    samples = eng.img2img(init_image, c, uc, steps, strength, cfg_scale, enc_noise=enc_noise, fwd_noise=fwd_noise)
+    if not decode:
+        return None, samples
+    x = eng.decode_first_stage(samples)
+    return ops.affine_cast(x, 0.5, 0.5, torch.float32, 0.0, 1.0), samples

@@ -118,6 +118,21 @@ class OpenAIWrapper(nn.Module):
         return self.diffusion_model(x, timesteps=t, context=c.get("crossattn", None), y=c.get("vector", None), **kwargs)
 
 
+class Img2ImgDiscretizationWrapper:
+    """scripts/demo/discretization.py:11-32 (installed on the sampler by init_sampling, sdxl_image_generator_utils.py:398-403):
+    keeps the last max(int(strength * len), 1) sigmas of the descending list, i.e. img2img starts part-way down the schedule."""
+
+    def __init__(self, discretization, strength: float = 1.0):
+        assert 0.0 <= strength <= 1.0
+        self.discretization = discretization
+        self.strength = strength
+
+    def __call__(self, *args, **kwargs):
+        sigmas = torch.flip(self.discretization(*args, **kwargs), (0,))
+        sigmas = sigmas[: max(int(self.strength * len(sigmas)), 1)]
+        return torch.flip(sigmas, (0,))
+
+
 class EulerEDMSampler:
     """sampling.py:29-219,309-318 with s_churn = 0 (the reference's default): Euler steps on the EDM ODE."""
 
@@ -165,6 +180,24 @@ class DiffusionEngine(nn.Module):
     @torch.no_grad()
     def decode_first_stage(self, z):
         return self.first_stage_model.decode(1.0 / self.scale_factor * z)
+
+    @torch.no_grad()
+    def encode_first_stage(self, x, noise=None):
+        """sgm/models/diffusion.py:139-151: scale_factor * posterior.sample() (the SDXL first stage is
+        AutoencoderKLInferenceWrapper, whose encode samples the posterior); `noise` makes the sample explicit."""
+        return self.scale_factor * self.first_stage_model.encode(x).sample(noise)
+
+    @torch.no_grad()
+    def img2img(self, img, cond: Dict, uc: Dict, steps: int, strength: float, cfg_scale: float, enc_noise=None, fwd_noise=None):
+        """do_img2img, sdxl_image_generator_utils.py:989-1016 (the face-fix re-entry of BASELINE config 5 is this call on a crop,
+        strength 0.3): encode, noise to sigma_0 of the pruned schedule, Euler-EDM over the remaining sigmas."""
+        z = self.encode_first_stage(img, enc_noise)
+        smp = EulerEDMSampler(steps, VanillaCFG(cfg_scale), device=z.device)
+        smp.discretization = Img2ImgDiscretizationWrapper(smp.discretization, strength=strength)
+        sigmas = smp.discretization(steps, device=z.device)
+        noise = torch.randn_like(z) if fwd_noise is None else fwd_noise
+        noised_z = (z + noise * sigmas[0]) / torch.sqrt(1.0 + sigmas[0] ** 2.0)
+        return smp(lambda inp, sigma, c: self.denoiser(self.model, inp, sigma, c), noised_z, cond=cond, uc=uc)
 
     @torch.no_grad()
     def sample(self, x, cond: Dict, uc: Dict, steps: int, cfg_scale: float):

@@ -660,11 +660,49 @@ def g_sgm_trajectory():
          sigmas=smp.discretization(5), table=den.sigmas, x=x, img=img)
 
 
+def g_sgm_img2img():
+    """SDXL img2img (the face-fix re-entry of config 5): the numeric core of do_img2img
+    (sdxl_pipeline/sdxl_image_generator_utils.py:906-1025) through the reference's own pieces - AutoencoderKL encoder moments ->
+    posterior sample x scale_factor (sgm/models/diffusion.py:139-151), Img2ImgDiscretizationWrapper pruning
+    (scripts/demo/discretization.py:11-32), noising z + noise * sigma_0 then / sqrt(1 + sigma_0^2) (:1003-1009), EulerEDMSampler
+    over the pruned sigmas with VanillaCFG, decode."""
+    SU, DN, DZ, GD, SM, WR = _import_sgm()
+    SM.denoising_status_queue = types.SimpleNamespace(put=lambda *a, **k: None)
+    from scripts.demo.discretization import Img2ImgDiscretizationWrapper
+    from ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+    unet = SU.UNetModel(**TINY_SGM_UNET)
+    synth_fill_(unet, SEED, prefix="sgm_unet.")
+    model = WR.OpenAIWrapper(unet)
+    den = DN.DiscreteDenoiser(scaling_config={"target": "sgm.modules.diffusionmodules.denoiser_scaling.EpsScaling"}, num_idx=1000,
+                              discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"})
+    S, strength = 10, 0.6
+    smp = SM.EulerEDMSampler(discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"},
+                             num_steps=S, guider_config={"target": "sgm.modules.diffusionmodules.guiders.VanillaCFG",
+                                                         "params": {"scale": 5.0}}, device="cpu")
+    smp.discretization = Img2ImgDiscretizationWrapper(smp.discretization, strength=strength)  # sdxl_image_generator_utils.py:398-403
+    B, L = 2, 16
+    c = {"crossattn": synth_input("sgmi2i.c", (B, 77, 128), SEED), "vector": synth_input("sgmi2i.cv", (B, 96), SEED)}
+    uc = {"crossattn": synth_input("sgmi2i.uc", (B, 77, 128), SEED), "vector": synth_input("sgmi2i.ucv", (B, 96), SEED)}
+    img = synth_input("sgmi2i.img", (B, 3, 2 * L, 2 * L), SEED, 0.5).clamp(-1, 1)  # TINY_DD has one down level: 32x32 -> 16x16
+    enc_noise = synth_input("sgmi2i.enc_noise", (B, 4, L, L), SEED)
+    noise = synth_input("sgmi2i.noise", (B, 4, L, L), SEED)
+    ae = _make_ae(TINY_DD)
+    with fp32_forward(), contextlib.redirect_stdout(open(os.devnull, "w")):
+        post = DiagonalGaussianDistribution(ae.quant_conv(ae.encoder(img)))
+        z = 0.13025 * (post.mean + post.std * enc_noise)        # posterior.sample() with the noise made explicit
+        sigmas = smp.discretization(smp.num_steps)
+        noised_z = (z + noise * sigmas[0]) / torch.sqrt(1.0 + sigmas[0] ** 2.0)
+        x = smp(lambda inp, sigma, cc: den(model, inp, sigma, cc), noised_z.clone(), cond=c, uc=uc)
+        out = ae.decode(x / 0.13025)
+    save("traj_sdxl_img2img", dict(B=B, L=L, S=S, strength=strength, cfg=5.0, seed=SEED, unet=TINY_SGM_UNET, dd=TINY_DD, scale_factor=0.13025),
+         sigmas=sigmas, z=z, noised_z=noised_z, x=x, img=out)
+
+
 CASES = dict(alphas_doc=g_alphas_doc, param_contract=g_param_contract, groupnorm=g_groupnorm, timestep_embedding=g_timestep_embedding, resblock=g_resblock, updown=g_updown,
              attention=g_attention, transformer=g_transformer, unet_tiny=g_unet_tiny, unet_small_sd=g_unet_small_sd,
              vae_blocks=g_vae_blocks, vae_tiny=g_vae_tiny, schedules=g_schedules, trajectories=g_trajectories)
 CASES.update(controlnet_hook=g_controlnet_hook, controlnet=g_controlnet)
-CASES.update(sgm_unet_tiny=g_sgm_unet_tiny, sgm_unet_small=g_sgm_unet_small, sgm_trajectory=g_sgm_trajectory)
+CASES.update(sgm_unet_tiny=g_sgm_unet_tiny, sgm_unet_small=g_sgm_unet_small, sgm_trajectory=g_sgm_trajectory, sgm_img2img=g_sgm_img2img)
 FULL = dict(controlnet_sd15_full=g_controlnet_sd15_full, unet_sd15_full=g_unet_sd15_full, vae_sd15_full=g_vae_sd15_full, sgm_unet_full=g_sgm_unet_full)
 
 if __name__ == "__main__":

@@ -751,10 +751,25 @@ def sdxl_denoise(net_fn, table, x, sigma, cond: dict, uc: dict, cfg_scale: float
     return x_u + cfg_scale * (x_c - x_u)
 
 
-def sdxl_sample_euler_edm(net_fn, x, cond, uc, num_steps: int, cfg_scale: float):
+def img2img_prune_sigmas(sigmas, strength: float):
+    """Img2ImgDiscretizationWrapper.__call__ scripts/demo/discretization.py:23-32: keep the LAST max(int(strength * len), 1)
+    entries of the descending sigma list (which ends with the appended 0)."""
+    s = torch.flip(sigmas, (0,))
+    s = s[: max(int(strength * len(s)), 1)]
+    return torch.flip(s, (0,))
+
+
+def sdxl_img2img_latents(vae_sd: SD, dd: dict, img, enc_noise, fwd_noise, sigmas, scale_factor: float = 0.13025):
+    """do_img2img sdxl_image_generator_utils.py:989-1009: z = scale_factor * posterior.sample() (sgm/models/diffusion.py:139-151);
+    noised_z = (z + noise * sigma_0) / sqrt(1 + sigma_0^2) (the sampler multiplies the same factor back, sampling.py:83)."""
+    z = scale_factor * gaussian_sample(autoencoder_encode_moments(vae_sd, dd, img), enc_noise)
+    return z, (z + fwd_noise * sigmas[0]) / torch.sqrt(1.0 + sigmas[0] ** 2.0)
+
+
+def sdxl_sample_euler_edm(net_fn, x, cond, uc, num_steps: int, cfg_scale: float, sigmas=None):
     """EulerEDMSampler (sampling.py:147-219,309-318) with s_churn = 0: x *= sqrt(1 + sigma_0^2) (:83); per step
-    d = (x - denoised)/sigma, x += d * (sigma_next - sigma)."""
-    sigmas = legacy_ddpm_sigmas(num_steps)
+    d = (x - denoised)/sigma, x += d * (sigma_next - sigma).  `sigmas`: an already pruned list (img2img)."""
+    sigmas = legacy_ddpm_sigmas(num_steps) if sigmas is None else sigmas
     table = discrete_denoiser_table()
     x = x * torch.sqrt(1.0 + sigmas[0] ** 2.0)
     s_in = x.new_ones([x.shape[0]])

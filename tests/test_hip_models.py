@@ -312,6 +312,28 @@ def test_sdxl_trajectory_euler_edm():
     assert (img.cpu() - g["img"]).abs().max().item() < 4e-3
 
 
+def test_sdxl_img2img_trajectory():
+    """SDXL img2img (BASELINE config 5's face-fix re-entry): VAE encode -> pruned-schedule Euler-EDM -> decode vs the reference"""
+    from cremage_amd import pipeline as P
+    from cremage_amd.ldm_hip.vae import AutoencoderKL
+    from cremage_amd.sgm_hip.sampling import DiffusionEngine
+    from cremage_amd.sgm_hip.unet import UNetModel
+    meta, g = load_golden("traj_sdxl_img2img")
+    unet = synth_fill_(UNetModel(**meta["unet"]), meta["seed"], prefix="sgm_unet.")
+    vae = synth_fill_(AutoencoderKL(meta["dd"], None, 4), meta["seed"], prefix="vae.")
+    eng = DiffusionEngine(unet, vae, meta["scale_factor"]).to(DEV).eval()
+    B, L, seed = meta["B"], meta["L"], meta["seed"]
+    c = {"crossattn": synth_input("sgmi2i.c", (B, 77, 128), seed).to(DEV), "vector": synth_input("sgmi2i.cv", (B, 96), seed).to(DEV)}
+    uc = {"crossattn": synth_input("sgmi2i.uc", (B, 77, 128), seed).to(DEV), "vector": synth_input("sgmi2i.ucv", (B, 96), seed).to(DEV)}
+    img = synth_input("sgmi2i.img", (B, 3, 2 * L, 2 * L), seed, 0.5).clamp(-1, 1).to(DEV)
+    en, fn = synth_input("sgmi2i.enc_noise", (B, 4, L, L), seed).to(DEV), synth_input("sgmi2i.noise", (B, 4, L, L), seed).to(DEV)
+    close(eng.encode_first_stage(img, en), g["z"], 1e-3, "sdxl img2img z")
+    images, x = P.img2img_sdxl(eng, img, c, uc, steps=meta["S"], strength=meta["strength"], cfg_scale=meta["cfg"], enc_noise=en, fwd_noise=fn)
+    close(x, g["x"], 2e-3, "sdxl img2img latent")
+    ref = ((g["img"] + 1) / 2).clamp(0, 1)
+    assert (images.cpu() - ref).abs().max().item() < 2e-3
+
+
 @pytest.mark.parametrize("dtype", [BF])
 def test_sgm_unet_sdxl_full(dtype):
     """Full-size SDXL UNet (2 567.46 M parameters), B=2, 128x128 latent (1024^2 image) vs the reference's sgm UNetModel"""

@@ -246,6 +246,28 @@ def test_sdxl_schedule_and_trajectory():
     assert max_abs(R.decode_first_stage(vsd, meta["dd"], x, meta["scale_factor"]), g["img"]) < 2e-3
 
 
+def test_sdxl_img2img_trajectory():
+    """SDXL img2img (config 5's face-fix re-entry): pruned sigmas, noised latent, Euler-EDM trajectory, decoded image"""
+    meta, g = load_golden("traj_sdxl_img2img")
+    from cremage_amd.ldm_hip.vae import AutoencoderKL
+    from cremage_amd.sgm_hip.unet import UNetModel
+    sig = R.img2img_prune_sigmas(R.legacy_ddpm_sigmas(meta["S"]), meta["strength"])
+    assert sig.shape == g["sigmas"].shape and max_abs(sig, g["sigmas"]) < 1e-6
+    usd = synth_state_dict(UNetModel(**meta["unet"]), meta["seed"], "sgm_unet.")
+    vsd = synth_state_dict(AutoencoderKL(meta["dd"], None, 4), meta["seed"], "vae.")
+    B, L, seed = meta["B"], meta["L"], meta["seed"]
+    c = {"crossattn": synth_input("sgmi2i.c", (B, 77, 128), seed), "vector": synth_input("sgmi2i.cv", (B, 96), seed)}
+    uc = {"crossattn": synth_input("sgmi2i.uc", (B, 77, 128), seed), "vector": synth_input("sgmi2i.ucv", (B, 96), seed)}
+    img = synth_input("sgmi2i.img", (B, 3, 2 * L, 2 * L), seed, 0.5).clamp(-1, 1)
+    z, nz = R.sdxl_img2img_latents(vsd, meta["dd"], img, synth_input("sgmi2i.enc_noise", (B, 4, L, L), seed),
+                                   synth_input("sgmi2i.noise", (B, 4, L, L), seed), sig, meta["scale_factor"])
+    assert max_abs(z, g["z"]) < 1e-4 and max_abs(nz, g["noised_z"]) < 1e-4
+    net = lambda x, t, ctx, yv: R.sgm_unet_forward(usd, meta["unet"], x, t.float(), ctx, yv)
+    x = R.sdxl_sample_euler_edm(net, nz, c, uc, meta["S"], meta["cfg"], sigmas=sig)
+    assert max_abs(x, g["x"]) < 2e-3
+    assert max_abs(R.decode_first_stage(vsd, meta["dd"], x, meta["scale_factor"]), g["img"]) < 2e-3
+
+
 def test_controlnet_hook_oracle():
     """oracle's `control=` path (cldm.py:57-65) against the reference's ControlledUnetModel"""
     meta, g = load_golden("hook_controlnet")
