@@ -789,16 +789,20 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
 }
 
 // Tile / pipeline configuration of the LDS-DMA kernel, by how many blocks the problem yields (256 CUs):
-//   A  128 x BN tile, 4 waves, 2-deep ring   : >= ~1.5 blocks per CU; two blocks share a CU and hide each other's latencies
-//   B  128 x BN tile, 8 waves (in-block split-K), 3-deep ring : about one block per CU
-//   C   64 x BN tile, 8 waves, 4-deep ring   : few 128-row tiles (16x16 / 8x8 levels): twice the blocks, all CUs busy
+//   A  128 x BN tile, 4 waves, 2-deep ring  : >= ~1.5 blocks per CU (after split-K); two blocks share a CU and hide each
+//                                             other's latencies
+//   D   64 x BN tile, 4 waves, 2-deep ring  : 192..383 tiles of 128 rows and a short K: twice the blocks -> two per CU again
+//                                             (4096x1280x1280: A 26.7, 8-wave 128-row variant 25.5, D 23.6 us)
+//   C   64 x BN tile, 8 waves (two k-groups, folded through LDS), 4-deep ring : < 192 tiles (16x16 / 8x8 token GEMMs): one
+//                                             block per CU at most, so the waves and the ring depth come from inside the block
+//                                             (2048x1280x1280: A 24.7, C 16.7 us)
 template <int WNT, int NSPLIT, typename AT, typename YT, bool CONV>
 int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   constexpr int BN = 32 * WNT;
   constexpr bool GLDS = (NSPLIT == 1) && (sizeof(AT) == 2);
   p.zero_page = (const bf16*)ctx->zero_page;
   p.tiles_n = (p.N + BN - 1) / BN;
-  static const int force = getenv("CRG_GEMM_CFG") ? atoi(getenv("CRG_GEMM_CFG")) : 0;  // dev knob: 1 = A, 2 = B, 3 = C
+  static const int force = getenv("CRG_GEMM_CFG") ? atoi(getenv("CRG_GEMM_CFG")) : 0;  // dev knob: 1 = A, 3 = C, 4 = D
   // split-K first, on 128-row tiles: a long K is the cheapest source of blocks.  Only problems that stay below ~1 block per
   // CU after that (short K) change the tile / wave configuration.
   p.tiles_m = (p.M + 127) / 128;
@@ -807,10 +811,10 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   if (GLDS && p.splits == 1) {
     const long blocks = (long)p.tiles_m * p.tiles_n * batch;
     if (blocks < 192) cfg = 3;
-    else if (blocks < 384) cfg = 2;
+    else if (blocks < 384) cfg = 4;
   }
   if (GLDS && force) cfg = force;
-  if (cfg == 3) {
+  if (cfg == 3 || cfg == 4) {
     p.tiles_m = (p.M + 63) / 64;
     p.splits = force ? choose_splits(p, p.tiles_n * p.tiles_m, batch) : 1;
   }
@@ -822,7 +826,7 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   int rc;
   if constexpr (GLDS) {
     if (cfg == 3) rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 4, 2, 2>(ctx, st, p, batch, wk);
-    else if (cfg == 2) rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 3, 4, 2>(ctx, st, p, batch, wk);
+    else if (cfg == 4) rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 2, 2, 1>(ctx, st, p, batch, wk);
     else rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 2, 4, 1>(ctx, st, p, batch, wk);
   } else {
     rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 2, 4, 1>(ctx, st, p, batch, wk);

@@ -58,9 +58,9 @@ DTYPES = [BF, torch.float32]
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(128, 160, 64), (300, 320, 328), (77, 128, 768), (8, 1280, 320), (1000, 200, 72), (130, 36, 40),
                                    # one shape per tile configuration of the LDS-DMA kernel (gemm_conv.hip `launch`):
-                                   (3000, 1280, 320),   # 192 tiles, short K          -> B (8 waves, in-block split-K)
+                                   (3000, 1280, 320),   # 192 tiles, short K          -> D (64-row tiles, 4 waves)
                                    (8200, 1280, 136),   # 520 tiles                   -> A (4 waves, 2 blocks per CU)
-                                   (2048, 640, 1280),   # 64 tiles, short K           -> C (64-row tiles)
+                                   (2048, 640, 1280),   # 64 tiles, short K           -> C (64-row tiles, 8 waves)
                                    (520, 320, 4096)])   # 10 tiles, long K            -> A + split-K
 def test_linear_shapes(dtype, M, N, K):
     from cremage_amd import ops
@@ -163,7 +163,7 @@ def test_conv2d(dtype, case):
 
 @pytest.mark.parametrize("N,C,Co,hw", [(2, 64, 320, 96), (4, 64, 320, 128), (1, 64, 640, 40)])
 def test_conv2d_tile_configs(N, C, Co, hw):
-    """bf16 3x3 convs sized to land on configurations B (288 blocks), A (1024 blocks) and C (130 tiles of 64 rows)."""
+    """bf16 3x3 convs sized to land on configurations D (288 tiles of 128 rows), A (1024 blocks) and C (26 tiles of 128 rows)."""
     from cremage_amd import ops
     x, w, b = rnd(N, C, hw, hw, seed=30), rnd(Co, C, 3, 3, seed=31, scale=(C * 9) ** -0.5), rnd(Co, seed=32)
     res = rnd(N, Co, hw, hw, seed=33)

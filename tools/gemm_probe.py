@@ -17,6 +17,7 @@ shapes = {
     "gemm": [(32768, 320, 2880), (32768, 2560, 320), (8192, 640, 640), (8192, 5120, 640), (2048, 1280, 1280), (32768, 320, 320),
              (2048, 10240, 1280), (2048, 1280, 5120), (512, 10240, 1280), (512, 1280, 5120), (8192, 640, 2560),
              (512, 1280, 1280), (512, 2560, 1280), (616, 1280, 768), (616, 640, 768), (2048, 2560, 1280), (8192, 1280, 640)],
+    "mid": [(4096, 1280, 1280), (8192, 640, 640), (2048, 1280, 1280), (4096, 1280, 640), (16384, 640, 640), (4096, 640, 1280), (8192, 1280, 640)],
     "ksweep": [(2048, 1280, k) for k in (64, 128, 320, 640, 1280, 2560)] + [(8192, 640, k) for k in (64, 128, 320, 640, 1280, 2560)],
 }[a.kind]
 for sh in (shapes[-a.only:] if a.only > 0 else shapes):
