@@ -53,6 +53,7 @@ class ConvArgs(C.Structure):
         ("ksize", c_int), ("stride", c_int), ("pad_t", c_int), ("pad_l", c_int),
         ("upsample2x", c_int),
         ("x_dtype", c_int), ("y_dtype", c_int), ("prec", c_int),
+        ("x_lo", c_void_p),
     ]
 
 
@@ -73,6 +74,9 @@ SIGNATURES = {
     "crg_profile_end": (c_int, [c_void_p, c_void_p, C.POINTER(Profile)]),
     "crg_groupnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                               c_int, c_float, c_int, c_int]),
+    "crg_groupnorm_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                    c_int, c_float, c_int]),
+    "crg_split_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "crg_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int]),
     "crg_gemm": (c_int, [c_void_p, c_void_p, C.POINTER(GemmArgs)]),
     "crg_conv2d": (c_int, [c_void_p, c_void_p, C.POINTER(ConvArgs)]),

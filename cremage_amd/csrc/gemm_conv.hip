@@ -447,8 +447,11 @@ __device__ __forceinline__ void wait_vmcnt() {  // s_waitcnt vmcnt(N) only (expc
   __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
 }
 
-template <int WNT, typename YT, bool CONV, int STAGES, int WMT, int KG>
+template <int WNT, typename YT, bool CONV, int STAGES, int WMT, int KG, int NS = 1>
 __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
+  // NS = 2: split-bf16 (fp32-class) operands - the activations arrive pre-split as two bf16 planes (hi = bf16(x),
+  // lo = bf16(x - hi), written by the producing GroupNorm / split pass), the weights as their two packed planes; all four
+  // are staged by LDS-DMA and every fragment pair costs three MFMAs (hi*hi + hi*lo + lo*hi).
   // Block tile (32*WMT) x (32*WNT) x 64; 4*KG waves.  The 4 waves of a k-group tile the block 2 x 2 (each 16*WMT rows x
   // 16*WNT columns); with KG == 2 the second group multiplies the second 32-wide k-step of every k-tile (in-block
   // split-K: twice the waves per SIMD on the same LDS traffic - for grids that cannot put two blocks on a CU) and its
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
   constexpr int NW = 4 * KG;
   constexpr int XS_BYTES = BMT * 128;
   constexpr int WS_BYTES = BN * 128;
-  constexpr int STAGE_BYTES = XS_BYTES + WS_BYTES;
+  constexpr int STAGE_BYTES = NS * (XS_BYTES + WS_BYTES);  // [X hi][X lo][W hi][W lo]
   constexpr int XRG = BMT / 8, WRG = BN / 8;      // 8-row groups (one 1 KiB wave-instruction each)
   constexpr int XL = (XRG + NW - 1) / NW;         // DMA instructions per wave per k-tile (uniform: waves without a row
   constexpr int WL = (WRG + NW - 1) / NW;         // group left issue a dummy load so that vmcnt counts stay uniform)
@@ -480,6 +483,9 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
 
   const bf16* A = reinterpret_cast<const bf16*>(p.a) + (long)bz * p.a_bs;
   const bf16* Wp = p.w + (long)bz * p.w_bs;
+  // lo planes live at a fixed element distance from the hi planes (same layout): one offset each
+  const long a_lo_off = NS == 2 ? reinterpret_cast<const bf16*>(p.a_lo) - reinterpret_cast<const bf16*>(p.a) : 0;
+  const long w_lo_off = NS == 2 ? p.w_lo - p.w : 0;
   const bf16* zpage = p.zero_page;
 
   // this lane always stages LDS row (8*g + lane/8), physical chunk lane%8 of row group g = wave + NW*q;
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
 
   auto stage = [&](int buf) {
     char* xs = smem + buf * STAGE_BYTES;
-    char* ws = xs + XS_BYTES;
+    char* ws = xs + NS * XS_BYTES;
     const bool kok = kc < p.K;
     if (CONV) {
       const int kh = (p.ks == 3) ? (tap * 11) >> 5 : 0;
@@ -555,20 +561,37 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
         const bf16* src = ok ? base + (xrow_off[q] + (long)hs * p.W + wsrc) * Cs + cs : zpage;
         char* dst = (wave + NW * q) < XRG ? xs + (wave + NW * q) * 1024 : smem + DUMMY;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        if constexpr (NS == 2) {
+          const bf16* src2 = ok ? src + a_lo_off : zpage;
+          char* dst2 = (wave + NW * q) < XRG ? dst + XS_BYTES : smem + DUMMY;
+          __builtin_amdgcn_global_load_lds((gptr_t)src2, (lptr_t)dst2, 16, 0, 0);
+        }
       }
     } else {
 #pragma unroll
       for (int q = 0; q < XL; ++q) {
-        const bf16* src = (kok && xok[q]) ? A + xrow_off[q] + kc : zpage;
+        const bool ok = kok && xok[q];
+        const bf16* src = ok ? A + xrow_off[q] + kc : zpage;
         char* dst = (wave + NW * q) < XRG ? xs + (wave + NW * q) * 1024 : smem + DUMMY;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        if constexpr (NS == 2) {
+          const bf16* src2 = ok ? src + a_lo_off : zpage;
+          char* dst2 = (wave + NW * q) < XRG ? dst + XS_BYTES : smem + DUMMY;
+          __builtin_amdgcn_global_load_lds((gptr_t)src2, (lptr_t)dst2, 16, 0, 0);
+        }
       }
     }
 #pragma unroll
     for (int q = 0; q < WL; ++q) {
-      const bf16* src = (kok && wok[q]) ? Wp + wrow_off[q] + kc : zpage;
+      const bool ok = kok && wok[q];
+      const bf16* src = ok ? Wp + wrow_off[q] + kc : zpage;
       char* dst = (wave + NW * q) < WRG ? ws + (wave + NW * q) * 1024 : smem + DUMMY;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+      if constexpr (NS == 2) {
+        const bf16* src2 = ok ? src + w_lo_off : zpage;
+        char* dst2 = (wave + NW * q) < WRG ? dst + WS_BYTES : smem + DUMMY;
+        __builtin_amdgcn_global_load_lds((gptr_t)src2, (lptr_t)dst2, 16, 0, 0);
+      }
     }
     // advance to the next k-tile
     kc += BK;
@@ -625,7 +648,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
     }
   }
 
-  constexpr int LOADS = XL + WL;  // LDS-DMA instructions per wave per k-tile
+  constexpr int LOADS = NS * (XL + WL);  // LDS-DMA instructions per wave per k-tile
   constexpr int D = STAGES - 1;   // prefetch distance
 #pragma unroll
   for (int s = 0; s < D; ++s)
@@ -642,19 +665,33 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
     asm volatile("" ::: "memory");
     if (kt + D < nk) stage(nbuf);
     const char* xs = smem + buf * STAGE_BYTES;
-    const char* ws = xs + XS_BYTES;
+    const char* ws = xs + NS * XS_BYTES;
 #pragma unroll
     for (int k2 = 0; k2 < 2 / KG; ++k2) {
       const int ks = KG == 2 ? kg : k2;
-      bf16x8 xf[WMT], wf[WNT];
+      bf16x8 xf[WMT], wf[WNT], xl[NS == 2 ? WMT : 1], wl[NS == 2 ? WNT : 1];
 #pragma unroll
-      for (int j = 0; j < WMT; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xs + lds_off(wm * (16 * WMT) + j * 16 + frow, ks * 4 + fq));
+      for (int j = 0; j < WMT; ++j) {
+        const int off = lds_off(wm * (16 * WMT) + j * 16 + frow, ks * 4 + fq);
+        xf[j] = *reinterpret_cast<const bf16x8*>(xs + off);
+        if constexpr (NS == 2) xl[j] = *reinterpret_cast<const bf16x8*>(xs + XS_BYTES + off);
+      }
 #pragma unroll
-      for (int i = 0; i < WNT; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(ws + lds_off(wn * (16 * WNT) + i * 16 + frow, ks * 4 + fq));
+      for (int i = 0; i < WNT; ++i) {
+        const int off = lds_off(wn * (16 * WNT) + i * 16 + frow, ks * 4 + fq);
+        wf[i] = *reinterpret_cast<const bf16x8*>(ws + off);
+        if constexpr (NS == 2) wl[i] = *reinterpret_cast<const bf16x8*>(ws + WS_BYTES + off);
+      }
 #pragma unroll
       for (int i = 0; i < WNT; ++i)
 #pragma unroll
-        for (int j = 0; j < WMT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WMT; ++j) {
+          if constexpr (NS == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xl[j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
     }
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
     nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
@@ -843,6 +880,43 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   return 0;
 }
 
+// fp32-class operands that arrive as pre-split bf16 planes: LDS-DMA kernel with NS = 2, 128 x BN tile, 8 waves in two
+// k-groups, 2-deep ring (4 planes x 2 stages fill the LDS: one block per CU, so the second wave per SIMD comes from the k-groups).
+template <int WNT, bool CONV>
+int launch_planes(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
+  constexpr int BN = 32 * WNT;
+  constexpr size_t lds = (size_t)2 * 2 * (128 + BN) * 128 + 1024;
+  p.zero_page = (const bf16*)ctx->zero_page;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  p.tiles_m = (p.M + 127) / 128;
+  p.splits = choose_splits(p, p.tiles_n * p.tiles_m, batch);
+  if (p.splits > 1) {
+    p.slab = (float*)crg_scratch(ctx, (size_t)batch * p.splits * p.M * p.N * sizeof(float));
+    if (!p.slab) return crg_fail(ctx, -12, "gemm: out of scratch for %d split-K slabs", p.splits);
+  }
+  choose_xcd_partition(p, wk);
+  void (*kern)(GemmP) = gemm_glds_kernel<WNT, float, CONV, 2, 4, 2, 2>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", lds, hipGetErrorString(e));
+    attr_set = true;
+  }
+  {
+    crg_prof_scope ps(ctx, st, CONV ? CRG_K_CONV_X3 : CRG_K_GEMM_X3, wk.flops, wk.bytes);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_n * p.tiles_m * p.splits, batch, 1), dim3(512), lds, st, p);
+    CRG_CHECK_LAUNCH(ctx, "gemm(planes)");
+  }
+  if (p.splits > 1) {
+    const long total4 = (long)p.M * (p.N >> 2);
+    const int rg = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+    crg_prof_scope ps(ctx, st, CRG_K_SPLITK, (double)batch * p.splits * p.M * p.N, (double)batch * p.M * p.N * (4.0 * p.splits + 4));
+    hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(rg, batch), dim3(256), 0, st, p);
+    CRG_CHECK_LAUNCH(ctx, "splitk_reduce");
+  }
+  return 0;
+}
+
 template <int NSPLIT, typename AT, typename YT, bool CONV>
 int launch_wnt(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   // 160-wide tiles when they divide N (all UNet widths are multiples of 320), else 128-wide.
@@ -860,6 +934,11 @@ int dispatch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, int a_dtype, int
     if (a_dtype == CRG_F32 && y_dtype == CRG_BF16) return launch_wnt<1, float, bf16, CONV>(ctx, st, p, batch, wk);
     if (a_dtype == CRG_F32 && y_dtype == CRG_F32) return launch_wnt<1, float, float, CONV>(ctx, st, p, batch, wk);
   } else if (prec == CRG_PREC_BF16X3) {
+    if (a_dtype == CRG_BF16 && y_dtype == CRG_F32 && p.a_lo && !p.a_is_weight && p.epi == CRG_EPI_NONE) {
+      if (p.N <= 32) return launch_planes<1, CONV>(ctx, st, p, batch, wk);
+      if (p.N % 160 == 0) return launch_planes<5, CONV>(ctx, st, p, batch, wk);
+      return launch_planes<4, CONV>(ctx, st, p, batch, wk);
+    }
     if (a_dtype == CRG_F32 && y_dtype == CRG_F32) return launch_wnt<2, float, float, CONV>(ctx, st, p, batch, wk);
     if (!CONV && a_dtype == CRG_BF16 && y_dtype == CRG_F32 && p.a_is_weight)
       return launch_wnt<2, bf16, float, false>(ctx, st, p, batch, wk);
@@ -912,8 +991,12 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
   const int Hv = a->upsample2x ? 2 * a->H : a->H, Wv = a->upsample2x ? 2 * a->W : a->W;
   CRG_REQUIRE(ctx, a->Ho > 0 && a->Wo > 0 && (a->Ho - 1) * a->stride - a->pad_t < Hv && (a->Wo - 1) * a->stride - a->pad_l < Wv,
               "conv2d: output %dx%d inconsistent with input %dx%d stride %d", a->Ho, a->Wo, Hv, Wv, a->stride);
+  if (a->x_lo) {
+    CRG_REQUIRE(ctx, a->prec == CRG_PREC_BF16X3 && a->x_dtype == CRG_BF16 && a->y_dtype == CRG_F32 && !a->x2 && ((uintptr_t)a->x_lo & 15) == 0,
+                "conv2d: pre-split activations (x_lo) need prec BF16X3, bf16 planes, fp32 output, no second input");
+  }
   GemmP p{};
-  p.a = a->x; p.x2 = a->x2; p.C1 = a->C1; p.C2 = a->C2; p.Ctot = Ctot;
+  p.a = a->x; p.a_lo = a->x_lo; p.x2 = a->x2; p.C1 = a->C1; p.C2 = a->C2; p.Ctot = Ctot;
   p.w = (const bf16*)a->w; p.w_lo = (const bf16*)a->w_lo; p.ldw = (long)a->ksize * a->ksize * Ctot; p.w_bs = 0;
   p.bias = a->bias; p.bias_mode = a->bias ? CRG_BIAS_COL : CRG_BIAS_NONE;
   p.res = a->residual; p.ldr = a->Cout; p.r_bs = 0;

@@ -124,7 +124,10 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const T* __restrict__ x, 
                                                        int groups, int rows_per_block, int n_chunks,
                                                        const float* __restrict__ part, const float* __restrict__ kbuf,
                                                        const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float eps, int silu, T* __restrict__ y) {
+                                                       const float* __restrict__ beta, float eps, int silu, T* __restrict__ y,
+                                                       bf16* __restrict__ yh, bf16* __restrict__ yl) {
+  // yh / yl (fp32 inputs only): write the result as two bf16 planes, hi = bf16(f) and lo = bf16(f - hi), instead of y - the
+  // operand format of the split-bf16 (fp32-class) LDS-DMA conv, so the split costs no extra pass over the tensor
   __shared__ float meanv[GN_MAX_GROUPS], rstdv[GN_MAX_GROUPS];
   const int n = blockIdx.y;
   const int t = threadIdx.x;
@@ -174,11 +177,31 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const T* __restrict__ x, 
   const T* base = second ? x2 + (long)n * HW * C2 + (c0 - C1) : x + (long)n * HW * C1 + c0;
   const int Cs = second ? C2 : C1;
   T* yb = y + (long)n * HW * C + c0;
+  const long plane0 = (long)n * HW * C + c0;
+  auto emit = [&](const float (&f)[8], long roff) {
+    if (yh) {
+      bf16x8 h8, l8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bf16 h = (bf16)f[e];
+        h8[e] = h;
+        l8[e] = (bf16)(f[e] - (float)h);
+      }
+      *reinterpret_cast<bf16x8*>(yh + plane0 + roff) = h8;
+      *reinterpret_cast<bf16x8*>(yl + plane0 + roff) = l8;
+    } else {
+      crg_vec8<T> o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.set(e, f[e]);
+      o.store(yb + roff);
+    }
+  };
   const int r_begin = blockIdx.x * rows_per_block;
   const int r_end = min(HW, r_begin + rows_per_block);
   int r = r_begin + rl;
   for (; r + rpi < r_end; r += 2 * rpi) {
-    crg_vec8<T> v0, v1, o0, o1;
+    crg_vec8<T> v0, v1;
+    float g0[8], g1[8];
     v0.load(base + (long)r * Cs);
     v1.load(base + (long)(r + rpi) * Cs);
 #pragma unroll
@@ -188,22 +211,23 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const T* __restrict__ x, 
         f0 = crg_silu_f(f0);
         f1 = crg_silu_f(f1);
       }
-      o0.set(e, f0);
-      o1.set(e, f1);
+      g0[e] = f0;
+      g1[e] = f1;
     }
-    o0.store(yb + (long)r * C);
-    o1.store(yb + (long)(r + rpi) * C);
+    emit(g0, (long)r * C);
+    emit(g1, (long)(r + rpi) * C);
   }
   for (; r < r_end; r += rpi) {
-    crg_vec8<T> v, o;
+    crg_vec8<T> v;
+    float g0[8];
     v.load(base + (long)r * Cs);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float f = v.get(e) * sc[e] + sf[e];
       if (silu) f = crg_silu_f(f);
-      o.set(e, f);
+      g0[e] = f;
     }
-    o.store(yb + (long)r * C);
+    emit(g0, (long)r * C);
   }
 }
 
@@ -370,9 +394,9 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__
 
 }  // namespace
 
-extern "C" int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* gamma,
-                             const float* beta, void* y, int N, int HW, int C, int groups, float eps, int fuse_silu,
-                             int dtype) {
+static int groupnorm_impl(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* gamma,
+                          const float* beta, void* y, bf16* yh, bf16* yl, int N, int HW, int C, int groups, float eps, int fuse_silu,
+                          int dtype) {
   if (!ctx) return -22;
   CRG_REQUIRE(ctx, N > 0 && HW > 0 && C > 0, "groupnorm: empty input");
   CRG_REQUIRE(ctx, groups > 0 && groups <= GN_MAX_GROUPS && C % groups == 0, "groupnorm: groups=%d C=%d unsupported", groups, C);
@@ -385,7 +409,7 @@ extern "C" int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const vo
   {
     const int gs = C / groups;
     const long vecs = (long)HW * (gs >> 3);
-    if (gs % 8 == 0 && C1 % gs == 0 && vecs <= 2560 && ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0) {
+    if (!yh && gs % 8 == 0 && C1 % gs == 0 && vecs <= 2560 && ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0) {
       hipStream_t st = (hipStream_t)stream;
       const double elems = (double)N * HW * C;
       crg_prof_scope ps(ctx, st, CRG_K_GN_APPLY, 8.0 * elems, elems * crg_dtype_size(dtype) * 2);
@@ -432,13 +456,28 @@ extern "C" int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const vo
     crg_prof_scope ps(ctx, st, CRG_K_GN_APPLY, 5.0 * elems, elems * es * 2);
     if (dtype == CRG_BF16)
       hipLaunchKernelGGL(gn_apply_kernel<bf16>, grid, dim3(threads), 0, st, (const bf16*)x, (const bf16*)x2, C1, C, HW, groups, rpc, chunks,
-                         part, kbuf, gamma, beta, eps, fuse_silu, (bf16*)y);
+                         part, kbuf, gamma, beta, eps, fuse_silu, (bf16*)y, (bf16*)nullptr, (bf16*)nullptr);
     else
       hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(threads), 0, st, (const float*)x, (const float*)x2, C1, C, HW, groups, rpc, chunks,
-                         part, kbuf, gamma, beta, eps, fuse_silu, (float*)y);
+                         part, kbuf, gamma, beta, eps, fuse_silu, (float*)y, yh, yl);
   }
   CRG_CHECK_LAUNCH(ctx, "groupnorm");
   return 0;
+}
+
+extern "C" int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* gamma,
+                             const float* beta, void* y, int N, int HW, int C, int groups, float eps, int fuse_silu,
+                             int dtype) {
+  return groupnorm_impl(ctx, stream, x, x2, C1, gamma, beta, y, nullptr, nullptr, N, HW, C, groups, eps, fuse_silu, dtype);
+}
+
+extern "C" int crg_groupnorm_split(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* gamma,
+                                   const float* beta, void* y_hi, void* y_lo, int N, int HW, int C, int groups, float eps,
+                                   int fuse_silu) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, y_hi && y_lo && (((uintptr_t)y_hi | (uintptr_t)y_lo) & 15) == 0, "groupnorm_split: output planes must be 16-byte aligned");
+  return groupnorm_impl(ctx, stream, x, x2, C1, gamma, beta, y_hi /* unused as y */, (bf16*)y_hi, (bf16*)y_lo, N, HW, C, groups, eps,
+                        fuse_silu, CRG_F32);
 }
 
 extern "C" int crg_layernorm(crg_ctx* ctx, void* stream, const void* x, const float* gamma, const float* beta, void* y,

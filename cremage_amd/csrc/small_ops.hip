@@ -352,6 +352,35 @@ extern "C" int crg_affine_cast(crg_ctx* ctx, void* stream, const void* x, void* 
   return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ hi, bf16* __restrict__ lo, long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 8), b = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+    bf16x8 h8, l8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = e < 4 ? a[e] : b[e - 4];
+      const bf16 h = (bf16)f;
+      h8[e] = h;
+      l8[e] = (bf16)(f - (float)h);
+    }
+    *reinterpret_cast<bf16x8*>(hi + i * 8) = h8;
+    *reinterpret_cast<bf16x8*>(lo + i * 8) = l8;
+  }
+}
+}  // namespace
+
+extern "C" int crg_split_bf16(crg_ctx* ctx, void* stream, const void* x, void* hi, void* lo, int64_t n) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, n > 0 && n % 8 == 0, "split_bf16: element count %ld must be a positive multiple of 8", (long)n);
+  CRG_REQUIRE(ctx, (((uintptr_t)x | (uintptr_t)hi | (uintptr_t)lo) & 15) == 0, "split_bf16: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  crg_prof_scope ps(ctx, st, CRG_K_ELEMENTWISE, 3.0 * n, 8.0 * n);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, st, (const float*)x, (bf16*)hi, (bf16*)lo, (long)(n / 8));
+  CRG_CHECK_LAUNCH(ctx, "split_bf16");
+  return 0;
+}
+
 extern "C" int crg_axpby(crg_ctx* ctx, void* stream, const void* x, void* y, int64_t n, float a, float b, int dtype) {
   if (!ctx) return -22;
   CRG_REQUIRE(ctx, n > 0, "axpby: empty");

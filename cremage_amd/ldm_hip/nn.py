@@ -21,8 +21,8 @@ def compute_dtype_of(x: torch.Tensor) -> torch.dtype:
 class GroupNorm32(nn.GroupNorm):
     """util.py:214-216 - statistics in fp32 whatever the storage dtype; optional fused SiLU."""
 
-    def forward(self, x, silu: bool = False, x2=None):
-        return ops.group_norm(x, self.weight, self.bias, self.num_groups, self.eps, silu=silu, x2=x2)
+    def forward(self, x, silu: bool = False, x2=None, split: bool = False):
+        return ops.group_norm(x, self.weight, self.bias, self.num_groups, self.eps, silu=silu, x2=x2, split=split)
 
 
 class GroupNorm(GroupNorm32):

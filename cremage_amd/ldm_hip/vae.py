@@ -21,6 +21,11 @@ from .. import ops
 from .nn import Conv2d, Normalize
 
 
+def _planes_ok(x, conv) -> bool:
+    """fp32-class activations feeding a conv the MFMA path handles (not the thin-channel kernels): use split bf16 planes."""
+    return x.dtype == torch.float32 and conv.in_channels % 8 == 0 and conv.in_channels >= 64 and conv.out_channels > 8
+
+
 class Upsample(nn.Module):
     def __init__(self, in_channels, with_conv):
         super().__init__()
@@ -30,7 +35,12 @@ class Upsample(nn.Module):
         self.conv = Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
 
     def forward(self, x):
-        return self.conv(x, upsample2x=True)  # nearest 2x folded into the conv gather (model.py:60-64)
+        # nearest 2x folded into the conv gather (model.py:60-64); fp32-class: the residual stream is split into bf16 planes
+        # first (one elementwise pass) so that the conv runs on the LDS-DMA kernel
+        if _planes_ok(x, self.conv):
+            hi, lo = ops.split_bf16(x)
+            return self.conv(hi, x_lo=lo, upsample2x=True)
+        return self.conv(x, upsample2x=True)
 
 
 class Downsample(nn.Module):
@@ -43,6 +53,9 @@ class Downsample(nn.Module):
 
     def forward(self, x):
         # F.pad(x, (0,1,0,1)) + stride-2 pad-0 conv (model.py:79-83) == asymmetric zero padding in the gather
+        if _planes_ok(x, self.conv):
+            hi, lo = ops.split_bf16(x)
+            return self.conv(hi, x_lo=lo, padding=(0, 0, 1, 1))
         return self.conv(x, padding=(0, 0, 1, 1))
 
 
@@ -67,6 +80,14 @@ class ResnetBlock(nn.Module):
                 self.nin_shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
 
     def forward(self, x, temb=None):
+        if _planes_ok(x, self.conv1) and _planes_ok(x, self.conv2):
+            # fp32-class: GroupNorm+swish writes the two bf16 planes the conv's LDS-DMA kernel stages (no fp32 round trip)
+            hi, lo = self.norm1(x, silu=True, split=True)
+            h = self.conv1(hi, x_lo=lo)
+            hi, lo = self.norm2(h, silu=True, split=True)
+            if self.in_channels != self.out_channels:
+                x = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x)
+            return self.conv2(hi, x_lo=lo, residual=x)
         h = self.conv1(self.norm1(x, silu=True))
         h = self.norm2(h, silu=True)
         if self.in_channels != self.out_channels:

@@ -226,8 +226,10 @@ def affine_cast(x: torch.Tensor, a: float, b: float, dtype: torch.dtype, lo: flo
 
 
 # ---------------------------------------------------------------------------------- norms
-def group_norm(x: torch.Tensor, weight, bias, groups: int, eps: float, silu: bool = False, x2: Optional[torch.Tensor] = None):
-    """GroupNorm(+SiLU) over a channels-last image; `x2` = second half of a virtual channel concat."""
+def group_norm(x: torch.Tensor, weight, bias, groups: int, eps: float, silu: bool = False, x2: Optional[torch.Tensor] = None,
+               split: bool = False):
+    """GroupNorm(+SiLU) over a channels-last image; `x2` = second half of a virtual channel concat.  With `split` (fp32
+    inputs only) the result is returned as the pair of bf16 planes (hi, lo) that conv2d(hi, ..., x_lo=lo) consumes."""
     _need_cuda(x, weight, bias, x2)
     x = to_channels_last(x)
     n, c1, hh, ww = x.shape
@@ -239,8 +241,15 @@ def group_norm(x: torch.Tensor, weight, bias, groups: int, eps: float, silu: boo
         c = c1 + x2.shape[1]
     if weight.numel() != c:
         raise L.CrgError(f"group_norm: {weight.numel()} gains for {c} channels")
-    y = empty_image(n, c, hh, ww, x.dtype, x.device)
     h = _h(x)
+    if split:
+        if x.dtype != torch.float32:
+            raise L.CrgError("group_norm(split=True) is the fp32-class path: fp32 input expected")
+        hi, lo = empty_image(n, c, hh, ww, torch.bfloat16, x.device), empty_image(n, c, hh, ww, torch.bfloat16, x.device)
+        L.check(L.load().crg_groupnorm_split(h, _st(), _p(x), _p(x2), c1, _p(f32_vec(weight)), _p(f32_vec(bias)), _p(hi), _p(lo), n, hh * ww, c,
+                                             groups, eps, int(silu)), h, "crg_groupnorm_split")
+        return hi, lo
+    y = empty_image(n, c, hh, ww, x.dtype, x.device)
     L.check(L.load().crg_groupnorm(h, _st(), _p(x), _p(x2), c1, _p(f32_vec(weight)), _p(f32_vec(bias)), _p(y), n, hh * ww, c,
                                    groups, eps, int(silu), _act_dt(x)), h, "crg_groupnorm")
     return y
@@ -346,15 +355,31 @@ def linear_transposed(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
 
 
 # ---------------------------------------------------------------------------------- conv
+def split_bf16(x: torch.Tensor):
+    """fp32 image -> (hi, lo) bf16 planes, hi = bf16(x), lo = bf16(x - hi): the fp32-class conv's operand format."""
+    _need_cuda(x)
+    x = to_channels_last(x)
+    n, c, hh, ww = x.shape
+    hi, lo = empty_image(n, c, hh, ww, torch.bfloat16, x.device), empty_image(n, c, hh, ww, torch.bfloat16, x.device)
+    h = _h(x)
+    L.check(L.load().crg_split_bf16(h, _st(), _p(x), _p(hi), _p(lo), x.numel()), h, "crg_split_bf16")
+    return hi, lo
+
+
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, padding=1,
            upsample2x: bool = False, x2: Optional[torch.Tensor] = None, cvec: Optional[torch.Tensor] = None,
-           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+           residual: Optional[torch.Tensor] = None, x_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Implicit-GEMM conv over channels-last images.
     padding: int (symmetric) or (top, left, bottom, right).  `upsample2x`: nearest-2x of the input is
     folded into the gather.  `x2`: second half of a virtual channel concat.  `cvec` fp32 [N, Cout] is
-    added per sample (timestep embedding); `residual` is added after."""
-    _need_cuda(x, weight, bias, x2, cvec, residual)
+    added per sample (timestep embedding); `residual` is added after.  `x_lo`: x is the bf16 hi plane of a pre-split
+    fp32 activation and x_lo its lo plane (group_norm(split=True) / split_bf16): fp32-class conv with fp32 output."""
+    _need_cuda(x, weight, bias, x2, cvec, residual, x_lo)
     x = to_channels_last(x)
+    if x_lo is not None:
+        x_lo = to_channels_last(x_lo)
+        if x.dtype != torch.bfloat16 or x_lo.dtype != torch.bfloat16 or x_lo.shape != x.shape or x2 is not None:
+            raise L.CrgError("conv2d: x / x_lo must be two bf16 planes of one shape (and no second input)")
     n, c1, hh, ww = x.shape
     c2 = 0
     if x2 is not None:
@@ -373,6 +398,8 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     ho = (hv + pt + pb - ks) // stride + 1
     wo = (wv + pl + pr - ks) // stride + 1
     if cin <= 8 or (cout <= 8 and (cin % 8 != 0 or cin < 64)):
+        if x_lo is not None:
+            raise L.CrgError("conv2d: thin-channel convs take the fp32 tensor, not split planes")
         if stride != 1 or upsample2x or x2 is not None or cvec is not None or residual is not None or (pt, pl, pb, pr) != (ks // 2,) * 4:
             raise L.CrgError("conv2d: thin-channel convs support only stride 1, 'same' padding, no fusions")
         y = empty_image(n, cout, ho, wo, x.dtype, x.device)
@@ -381,9 +408,10 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         L.check(L.load().crg_conv_small(h, _st(), _p(x), _p(w32), _p(f32_vec(bias)), _p(y), n, hh, ww, cin, cout, ks, _act_dt(x),
                                         _act_dt(y)), h, "crg_conv_small")
         return y
-    split = x.dtype == torch.float32
+    planes = x_lo is not None
+    split = planes or x.dtype == torch.float32
     hi, lo = packed_weight(weight, L.PACK_CONV, split)
-    y = empty_image(n, cout, ho, wo, x.dtype, x.device)
+    y = empty_image(n, cout, ho, wo, torch.float32 if planes else x.dtype, x.device)
     if residual is not None:
         residual = to_channels_last(residual)
         if residual.shape != y.shape or residual.dtype != y.dtype:
@@ -394,7 +422,8 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     a = L.ConvArgs(x=x.data_ptr(), x2=x2.data_ptr() if x2 is not None else None, C1=c1, C2=c2, w=hi.data_ptr(),
                    w_lo=lo.data_ptr() if lo is not None else None, bias=_p(f32_vec(bias)).value, cvec=_p(cvec).value,
                    cvec_ld=cvec.stride(0) if cvec is not None else 0, residual=_p(residual).value, y=y.data_ptr(), N=n, H=hh, W=ww, Cout=cout, Ho=ho, Wo=wo, ksize=ks, stride=stride,
-                   pad_t=pt, pad_l=pl, upsample2x=int(upsample2x), x_dtype=_act_dt(x), y_dtype=_act_dt(y), prec=_prec(x))
+                   pad_t=pt, pad_l=pl, upsample2x=int(upsample2x), x_dtype=_act_dt(x), y_dtype=_act_dt(y),
+                   prec=L.PREC_BF16X3 if planes else _prec(x), x_lo=x_lo.data_ptr() if planes else None)
     h = _h(x)
     L.check(L.load().crg_conv2d(h, _st(), C.byref(a)), h, "crg_conv2d")
     return y

@@ -91,6 +91,15 @@ int crg_profile_end(crg_ctx* ctx, void* stream, crg_profile* out);
 int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* gamma,
                   const float* beta, void* y, int N, int HW, int C, int groups, float eps, int fuse_silu,
                   int dtype);
+/* GroupNorm (+SiLU) of an fp32 image whose result is written as TWO bf16 planes, hi = bf16(y) and lo = bf16(y - hi) (each
+ * [N][HW][C]): the operand format of the fp32-class conv (crg_conv_args.x_lo).  Same statistics and arithmetic as
+ * crg_groupnorm with dtype CRG_F32; used by the VAE ResnetBlocks (model.py:128-148: norm -> swish -> conv). */
+int crg_groupnorm_split(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* gamma,
+                        const float* beta, void* y_hi, void* y_lo, int N, int HW, int C, int groups, float eps,
+                        int fuse_silu);
+/* fp32 tensor -> the same two bf16 planes (n elements, n % 8 == 0): for fp32-class convs whose input does not come from a
+ * GroupNorm (the VAE's Upsample / Downsample convs on the residual stream, model.py:60-64,79-86). */
+int crg_split_bf16(crg_ctx* ctx, void* stream, const void* x, void* hi, void* lo, int64_t n);
 
 /* ---- LayerNorm --------------------------------------------------------------------------
  * Replaces nn.LayerNorm(dim) in BasicTransformerBlock (attention.py:900-902,909-911).
@@ -142,6 +151,9 @@ typedef struct {
   int ksize, stride, pad_t, pad_l;  /* pad_b / pad_r are implied by Ho/Wo */
   int upsample2x;
   int x_dtype, y_dtype, prec;
+  const void* x_lo;                 /* BF16X3 with PRE-SPLIT activations: `x` is the bf16 hi plane, `x_lo` the bf16 lo plane
+                                       (same layout; written by crg_groupnorm_split / crg_split_bf16); x_dtype = CRG_BF16,
+                                       y_dtype = CRG_F32; NULL otherwise */
 } crg_conv_args;
 int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* args);
 
