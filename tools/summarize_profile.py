@@ -35,10 +35,13 @@ def slot_of(name):
     m = re.search(r"gemm_glds_kernel(?:<|ILi)(\d)", name)
     if m:
         conv = ("Lb1E" in name) or ("bool _Accum" in name) or bool(re.search(r", true[,>]", name))
+        # NS = 2 (last template argument): the split-plane fp32-class variant is accounted in the x3 slots
+        if re.search(r"Lb[01]E(?:Li\d+E){3}Li2E", name) or re.search(r"(?:true|false|E), \d+, \d+, \d+, 2>", name):
+            return "conv_x3" if conv else "gemm_x3"
         return ("conv_w" if conv else "gemm_w") + m.group(1)
     if "gemm_kernel" in name:
         return "conv_x3" if (("Lb1E" in name) or re.search(r", true[,>]", name)) else "gemm_x3"
-    for pat, slot in (("splitk_reduce", "splitk_reduce"), ("attn_kernel", "attention"), ("gn_stats", "gn_stats"), ("gn_apply", "gn_apply"),
+    for pat, slot in (("splitk_reduce", "splitk_reduce"), ("attn_kernel", "attention"), ("gn_stats", "gn_stats"), ("gn_apply", "gn_apply"), ("gn_small", "gn_apply"),
                       ("layernorm_kernel", "layernorm"), ("softmax_rows", "softmax"), ("conv_small", "conv_small")):
         if pat in name:
             return slot
