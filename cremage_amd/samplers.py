@@ -170,7 +170,7 @@ class LDMWrapperForKDiffusion(nn.Module):
 
 
 def to_d(x, sigma, denoised):
-    return (x - denoised) / append_dims(sigma, x.ndim)
+    return (x - denoised) / (append_dims(sigma, x.ndim) if torch.is_tensor(sigma) else sigma)
 
 
 def get_ancestral_step(sigma_from, sigma_to, eta=1.):
@@ -185,44 +185,56 @@ def default_noise_sampler(x):
     return lambda sigma, sigma_next: torch.randn_like(x)
 
 
+def _host_sigmas(sigmas, sigmas_host):
+    """The schedule as a CPU fp32 tensor for everything that steers the loop (comparisons, the ancestral split, the scalar
+    step sizes).  A 0-dim DEVICE tensor in a Python `if` / `min` is a device-to-host copy, i.e. a stream synchronisation per
+    step: the host then never runs ahead of the GPU and every step starts with the GPU idle for the host's launch latency
+    (measured: 40 syncs and ~15 ms of idle GPU per 300 ms batch).  The samplers pass the CPU copy they computed the schedule
+    from; without one the device tensor is copied once, before the loop."""
+    return sigmas.detach().float().cpu() if sigmas_host is None else sigmas_host
+
+
 @torch.no_grad()
 def sample_euler(model, x, sigmas, extra_args=None, callback=None, disable=None, s_churn=0., s_tmin=0., s_tmax=float('inf'),
-                 s_noise=1.):
+                 s_noise=1., sigmas_host=None):
     """sampling.py:118-143 (Algorithm 2 of Karras et al. 2022), including the per-step randn_like draw
     that keeps the global RNG stream aligned with the reference (:128)."""
     extra_args = {} if extra_args is None else extra_args
     s_in = x.new_ones([x.shape[0]])
+    sh = _host_sigmas(sigmas, sigmas_host)
     for i in range(len(sigmas) - 1):
-        gamma = min(s_churn / (len(sigmas) - 1), 2 ** 0.5 - 1) if s_tmin <= sigmas[i] <= s_tmax else 0.
+        gamma = min(s_churn / (len(sigmas) - 1), 2 ** 0.5 - 1) if s_tmin <= sh[i].item() <= s_tmax else 0.
         eps = torch.randn_like(x) * s_noise
-        sigma_hat = sigmas[i] * (gamma + 1)
+        sigma_hat = sh[i] * (gamma + 1)
         if gamma > 0:
-            x = x + eps * (sigma_hat ** 2 - sigmas[i] ** 2) ** 0.5
-        denoised = model(x, sigma_hat * s_in, **extra_args)
-        d = to_d(x, sigma_hat, denoised)
+            x = x + eps * ((sigma_hat ** 2 - sh[i] ** 2) ** 0.5).item()
+        denoised = model(x, (sigmas[i] * (gamma + 1)) * s_in, **extra_args)
+        d = to_d(x, sigma_hat.item(), denoised)
         if callback is not None:
             callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
-        dt = sigmas[i + 1] - sigma_hat
+        dt = (sh[i + 1] - sigma_hat).item()
         x = x + d * dt
     return x
 
 
 @torch.no_grad()
-def sample_euler_ancestral(model, x, sigmas, extra_args=None, callback=None, disable=None, eta=1., s_noise=1., noise_sampler=None):
+def sample_euler_ancestral(model, x, sigmas, extra_args=None, callback=None, disable=None, eta=1., s_noise=1., noise_sampler=None,
+                           sigmas_host=None):
     """sampling.py:147-163."""
     extra_args = {} if extra_args is None else extra_args
     noise_sampler = default_noise_sampler(x) if noise_sampler is None else noise_sampler
     s_in = x.new_ones([x.shape[0]])
+    sh = _host_sigmas(sigmas, sigmas_host)
     for i in range(len(sigmas) - 1):
         denoised = model(x, sigmas[i] * s_in, **extra_args)
-        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta=eta)
+        sigma_down, sigma_up = get_ancestral_step(sh[i], sh[i + 1], eta=eta)   # CPU fp32 scalars: no device round trip
         if callback is not None:
             callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
-        d = to_d(x, sigmas[i], denoised)
-        dt = sigma_down - sigmas[i]
+        d = to_d(x, sh[i].item(), denoised)
+        dt = (sigma_down - sh[i]).item()
         x = x + d * dt
-        if sigmas[i + 1] > 0:
-            x = x + noise_sampler(sigmas[i], sigmas[i + 1]) * s_noise * sigma_up
+        if sh[i + 1].item() > 0:
+            x = x + noise_sampler(sigmas[i], sigmas[i + 1]) * s_noise * float(sigma_up)
     return x
 
 
@@ -246,6 +258,16 @@ class KDiffusionSamplerBase(object):
     def compute_sigmas(self, n: int):
         return None
 
+    def compute_sigmas_host(self, n: int):
+        """The same schedule computed on the CPU from a cached CPU copy of alphas_cumprod (fp32, the arithmetic of the
+        reference run on a CPU device): steers the sampling loop without touching the device (see _host_sigmas)."""
+        m = self.ldm_model
+        acp = m.__dict__.get("_crg_acp_cpu")
+        if acp is None or acp[0] != m.alphas_cumprod._version:
+            acp = m.__dict__["_crg_acp_cpu"] = (m.alphas_cumprod._version, m.alphas_cumprod.detach().float().cpu())
+        sched = DiscreteSchedule(((1 - acp[1]) / acp[1]) ** 0.5, False)
+        return sched.get_sigmas(n)
+
     @torch.no_grad()
     def _sample_common_prep(self, S, batch_size, shape, conditioning=None, x0=None, unconditional_guidance_scale=1.,
                             unconditional_conditioning=None, **kwargs):
@@ -257,9 +279,11 @@ class KDiffusionSamplerBase(object):
         self.ldm_wrapper_model = LDMWrapperForKDiffusion(self.compviz_wrapper_model, conditioning, unconditional_conditioning,
                                                          unconditional_guidance_scale)
         self.sigmas = self.compute_sigmas(S)
+        self.sigmas_host = self.compute_sigmas_host(S)
         if "denoising_steps" in kwargs:  # partial denoising (img2img), :188-194
             t = kwargs["denoising_steps"]
             self.sigmas = self.sigmas[-(t + 1):]
+            self.sigmas_host = self.sigmas_host[-(t + 1):] if self.sigmas_host is not None else None
             assert self.sigmas.shape[0] == t + 1
 
     @torch.no_grad()
@@ -292,7 +316,7 @@ class EulerSampler(KDiffusionSamplerBase):
 
     @torch.no_grad()
     def do_sample(self):
-        return sample_euler(self.ldm_wrapper_model, self.x, self.sigmas), None
+        return sample_euler(self.ldm_wrapper_model, self.x, self.sigmas, sigmas_host=self.sigmas_host), None
 
 
 class EulerAncestralSampler(KDiffusionSamplerBase):
@@ -302,7 +326,8 @@ class EulerAncestralSampler(KDiffusionSamplerBase):
 
     @torch.no_grad()
     def do_sample(self):
-        return sample_euler_ancestral(self.ldm_wrapper_model, self.x, self.sigmas, noise_sampler=self.noise_sampler), None
+        return sample_euler_ancestral(self.ldm_wrapper_model, self.x, self.sigmas, noise_sampler=self.noise_sampler,
+                                      sigmas_host=self.sigmas_host), None
 
 
 def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=False):

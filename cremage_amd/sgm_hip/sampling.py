@@ -149,21 +149,25 @@ class EulerEDMSampler:
 
     @torch.no_grad()
     def __call__(self, denoiser, x, cond, uc=None, num_steps=None):
-        sigmas = self.discretization(self.num_steps if num_steps is None else num_steps, device=self.device)
+        n = self.num_steps if num_steps is None else num_steps
+        sigmas = self.discretization(n, device=self.device)
+        # CPU twin of the schedule for everything that steers the loop: a 0-dim device tensor in a Python comparison is a
+        # stream synchronisation per step (cremage_amd.samplers._host_sigmas)
+        sh = self.discretization(n, device="cpu").float()
         uc = cond if uc is None else uc
-        x = x * torch.sqrt(1.0 + sigmas[0] ** 2.0)
+        x = x * float(torch.sqrt(1.0 + sh[0] ** 2.0))
         num_sigmas = len(sigmas)
         s_in = x.new_ones([x.shape[0]])
         for i in range(num_sigmas - 1):
-            gamma = min(self.s_churn / (num_sigmas - 1), 2 ** 0.5 - 1) if self.s_tmin <= sigmas[i] <= self.s_tmax else 0.0
-            sigma, next_sigma = s_in * sigmas[i], s_in * sigmas[i + 1]
-            sigma_hat = sigma * (gamma + 1.0)
+            gamma = min(self.s_churn / (num_sigmas - 1), 2 ** 0.5 - 1) if self.s_tmin <= sh[i].item() <= self.s_tmax else 0.0
+            sigma_hat_h = sh[i] * (gamma + 1.0)
+            sigma_hat = s_in * (sigmas[i] * (gamma + 1.0))
             if gamma > 0:
                 eps = torch.randn_like(x) * self.s_noise
-                x = x + eps * append_dims(sigma_hat ** 2 - sigma ** 2, x.ndim) ** 0.5
+                x = x + eps * float((sigma_hat_h ** 2 - sh[i] ** 2) ** 0.5)
             denoised = self.denoise(x, denoiser, sigma_hat, cond, uc)
-            d = (x - denoised) / append_dims(sigma_hat, x.ndim)
-            x = x + append_dims(next_sigma - sigma_hat, x.ndim) * d
+            d = (x - denoised) / sigma_hat_h.item()
+            x = x + (sh[i + 1] - sigma_hat_h).item() * d
         return x
 
 
