@@ -18,6 +18,7 @@ shapes = {
              (2048, 10240, 1280), (2048, 1280, 5120), (512, 10240, 1280), (512, 1280, 5120), (8192, 640, 2560),
              (512, 1280, 1280), (512, 2560, 1280), (616, 1280, 768), (616, 640, 768), (2048, 2560, 1280), (8192, 1280, 640)],
     "mid": [(4096, 1280, 1280), (8192, 640, 640), (2048, 1280, 1280), (4096, 1280, 640), (16384, 640, 640), (4096, 640, 1280), (8192, 1280, 640)],
+    "res": [(32768, 320, 320), (8192, 640, 640), (2048, 1280, 1280)],
     "ksweep": [(2048, 1280, k) for k in (64, 128, 320, 640, 1280, 2560)] + [(8192, 640, k) for k in (64, 128, 320, 640, 1280, 2560)],
 }[a.kind]
 for sh in (shapes[-a.only:] if a.only > 0 else shapes):
@@ -34,6 +35,21 @@ for sh in (shapes[-a.only:] if a.only > 0 else shapes):
         w = (torch.randn(nn, k, device=dev) * 0.02).to(torch.bfloat16)
         f = lambda: ops.linear(x, w)
         fl = 2.0 * m * nn * k
+        if a.kind == "res":
+            bias = torch.zeros(nn, device=dev)
+            res = torch.randn(m, nn, device=dev).to(torch.bfloat16)
+            variants = [("plain", f), ("bias", lambda: ops.linear(x, w, bias)), ("bias+res", lambda: ops.linear(x, w, bias, residual=res))]
+            for tag, g in variants:
+                for _ in range(3):
+                    g()
+                torch.cuda.synchronize()
+                torch.zeros(1, device=dev)  # separator kernel for tools/trace_groups.py
+                for _ in range(a.reps):
+                    g()
+                torch.cuda.synchronize()
+                torch.zeros(1, device=dev)
+                print(f"res {sh} {tag}", flush=True)
+            continue
     for _ in range(3):
         f()
     torch.cuda.synchronize()
