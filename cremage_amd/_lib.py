@@ -91,6 +91,7 @@ SIGNATURES = {
     "crg_silu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int]),
     "crg_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "crg_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "crg_cfg_euler_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float]),
     "crg_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_int]),
     "crg_affine_cast": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int,
                                 c_int]),

@@ -381,6 +381,40 @@ extern "C" int crg_split_bf16(crg_ctx* ctx, void* stream, const void* x, void* h
   return 0;
 }
 
+namespace {
+// One fused sampler step (see include/crg_hip.h); the arithmetic follows the reference's operation order one rounding at a
+// time (no FMA contraction), so the result equals the chain of PyTorch elementwise kernels it replaces.
+__global__ __launch_bounds__(256) void cfg_euler_step_kernel(float* __restrict__ x, const float* __restrict__ eps,
+                                                             const float* __restrict__ noise, long n, float sigma, float dt,
+                                                             float cfg, float noise_scale) {
+#pragma clang fp contract(off)
+  const float c_out = -sigma;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float xv = x[i];
+    const float den_u = xv + eps[i] * c_out;
+    const float den_c = xv + eps[n + i] * c_out;
+    const float den = den_u + cfg * (den_c - den_u);
+    const float d = (xv - den) / sigma;
+    float xn = xv + d * dt;
+    if (noise) xn = xn + noise[i] * noise_scale;
+    x[i] = xn;
+  }
+}
+}  // namespace
+
+extern "C" int crg_cfg_euler_step(crg_ctx* ctx, void* stream, void* x, const void* eps, const void* noise, int64_t n, float sigma,
+                                  float dt, float cfg_scale, float noise_scale) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, n > 0 && x && eps, "cfg_euler_step: empty input");
+  CRG_REQUIRE(ctx, sigma > 0.f, "cfg_euler_step: sigma must be positive (got %g)", (double)sigma);
+  hipStream_t st = (hipStream_t)stream;
+  crg_prof_scope ps(ctx, st, CRG_K_ELEMENTWISE, 10.0 * n, 4.0 * n * (noise ? 5 : 4));
+  hipLaunchKernelGGL(cfg_euler_step_kernel, dim3(grid_for(n)), dim3(256), 0, st, (float*)x, (const float*)eps, (const float*)noise, (long)n,
+                     sigma, dt, cfg_scale, noise_scale);
+  CRG_CHECK_LAUNCH(ctx, "cfg_euler_step");
+  return 0;
+}
+
 extern "C" int crg_axpby(crg_ctx* ctx, void* stream, const void* x, void* y, int64_t n, float a, float b, int dtype) {
   if (!ctx) return -22;
   CRG_REQUIRE(ctx, n > 0, "axpby: empty");

@@ -520,6 +520,20 @@ def axpby_(y: torch.Tensor, x: torch.Tensor, a: float, b: float = 1.0) -> torch.
     return y
 
 
+def cfg_euler_step_(x: torch.Tensor, eps2: torch.Tensor, noise: Optional[torch.Tensor], sigma: float, dt: float, cfg_scale: float,
+                    noise_scale: float = 0.0) -> torch.Tensor:
+    """In-place fused sampler step (crg_cfg_euler_step): x fp32 [b, ...], eps2 fp32 [2b, ...] (uncond half first)."""
+    _need_cuda(x, eps2, noise)
+    if x.dtype != torch.float32 or eps2.dtype != torch.float32 or not x.is_contiguous() or not eps2.is_contiguous() \
+            or eps2.numel() != 2 * x.numel() or (noise is not None and (noise.dtype != torch.float32 or not noise.is_contiguous()
+                                                                         or noise.numel() != x.numel())):
+        raise L.CrgError("cfg_euler_step_: contiguous fp32 x [b,...], eps [2b,...] and noise [b,...] expected")
+    h = _h(x)
+    L.check(L.load().crg_cfg_euler_step(h, _st(), _p(x), _p(eps2), _p(noise), x.numel(), float(sigma), float(dt), float(cfg_scale),
+                                        float(noise_scale)), h, "crg_cfg_euler_step")
+    return x
+
+
 # ---------------------------------------------------------------------------------- profiling
 class profile:
     """Context manager: per-kernel device time (HIP events on the launch stream) + algorithmic FLOPs/bytes of

@@ -156,6 +156,19 @@ class LDMWrapperForKDiffusion(nn.Module):
             self._c_in = c_in
         return self._c_in
 
+    def eps_pair(self, x, sigma):
+        """The raw eps of the batch-doubled UNet call ([2b, ...], unconditional half first) for the fused sampler step:
+        the part of apply_model / CompVisDenoiser.forward before the scalings that crg_cfg_euler_step folds in."""
+        cv = self.compviz_model
+        x_in = torch.cat([x] * 2)
+        sigma_in = torch.cat([sigma] * 2)
+        _, c_in = [append_dims(v, x_in.ndim) for v in cv.get_scalings(sigma_in)]
+        return cv.get_eps(x_in * c_in, cv.sigma_to_t(sigma_in), cond=self._cat_cond())
+
+    def fused_step_ok(self, x) -> bool:
+        return (self.unconditional_conditioning is not None and self.unconditional_guidance_scale != 1. and x.is_cuda
+                and x.dtype == torch.float32 and isinstance(self.compviz_model, CompVisDenoiser))
+
     def apply_model(self, x, t, **kwargs):
         uc, scale = self.unconditional_conditioning, self.unconditional_guidance_scale
         if uc is None or scale == 1.:
@@ -202,12 +215,20 @@ def sample_euler(model, x, sigmas, extra_args=None, callback=None, disable=None,
     extra_args = {} if extra_args is None else extra_args
     s_in = x.new_ones([x.shape[0]])
     sh = _host_sigmas(sigmas, sigmas_host)
+    fused = callback is None and not extra_args and getattr(model, "fused_step_ok", lambda _x: False)(x)
+    if fused:
+        x = x.clone().contiguous()  # updated in place by the fused step
     for i in range(len(sigmas) - 1):
         gamma = min(s_churn / (len(sigmas) - 1), 2 ** 0.5 - 1) if s_tmin <= sh[i].item() <= s_tmax else 0.
         eps = torch.randn_like(x) * s_noise
         sigma_hat = sh[i] * (gamma + 1)
         if gamma > 0:
             x = x + eps * ((sigma_hat ** 2 - sh[i] ** 2) ** 0.5).item()
+        if fused:  # scalings + guidance + Euler update as one kernel (include/crg_hip.h: crg_cfg_euler_step)
+            from . import ops
+            e2 = model.eps_pair(x, (sigmas[i] * (gamma + 1)) * s_in)
+            ops.cfg_euler_step_(x, e2.contiguous(), None, sigma_hat.item(), (sh[i + 1] - sigma_hat).item(), model.unconditional_guidance_scale)
+            continue
         denoised = model(x, (sigmas[i] * (gamma + 1)) * s_in, **extra_args)
         d = to_d(x, sigma_hat.item(), denoised)
         if callback is not None:
@@ -225,7 +246,18 @@ def sample_euler_ancestral(model, x, sigmas, extra_args=None, callback=None, dis
     noise_sampler = default_noise_sampler(x) if noise_sampler is None else noise_sampler
     s_in = x.new_ones([x.shape[0]])
     sh = _host_sigmas(sigmas, sigmas_host)
+    fused = callback is None and not extra_args and getattr(model, "fused_step_ok", lambda _x: False)(x)
+    if fused:
+        x = x.clone().contiguous()  # updated in place by the fused step
     for i in range(len(sigmas) - 1):
+        if fused:  # scalings + guidance + Euler update + ancestral noise as one kernel (crg_cfg_euler_step)
+            from . import ops
+            e2 = model.eps_pair(x, sigmas[i] * s_in)
+            sigma_down, sigma_up = get_ancestral_step(sh[i], sh[i + 1], eta=eta)
+            noise = noise_sampler(sigmas[i], sigmas[i + 1]).contiguous() if sh[i + 1].item() > 0 else None
+            ops.cfg_euler_step_(x, e2.contiguous(), noise, sh[i].item(), (sigma_down - sh[i]).item(), model.unconditional_guidance_scale,
+                                s_noise * float(sigma_up))
+            continue
         denoised = model(x, sigmas[i] * s_in, **extra_args)
         sigma_down, sigma_up = get_ancestral_step(sh[i], sh[i + 1], eta=eta)   # CPU fp32 scalars: no device round trip
         if callback is not None:

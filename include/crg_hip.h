@@ -208,6 +208,16 @@ int crg_nhwc_to_nchw(crg_ctx* ctx, void* stream, const void* src, void* dst, int
 int crg_affine_cast(crg_ctx* ctx, void* stream, const void* x, void* y, int64_t n, float a, float b, float lo,
                     float hi, int src_dtype, int dst_dtype);
 
+/* One k-diffusion Euler / Euler-ancestral step of an eps-prediction model under classifier-free guidance, fp32, in place on x
+ * (the scalings, the guidance and the update that sit either side of the UNet call, as one kernel):
+ *   den_u = x + eps_u * (-sigma), den_c = x + eps_c * (-sigma)      CompVisDenoiser.forward      k_diffusion/external.py:111-114
+ *   den   = den_u + cfg_scale * (den_c - den_u)                      LDMWrapperForKDiffusion      ldm_wrapper_for_k_diffusion.py:99
+ *   d     = (x - den) / sigma;   x += d * dt                         sample_euler(_ancestral)     k_diffusion/sampling.py:134-142,157-160
+ *   x    += noise * noise_scale   (noise may be NULL)                ancestral noise              sampling.py:161-162
+ * eps: [2][n] fp32 (unconditional half first - the batch-doubled UNet output), x / noise: [n] fp32. */
+int crg_cfg_euler_step(crg_ctx* ctx, void* stream, void* x, const void* eps, const void* noise, int64_t n, float sigma,
+                       float dt, float cfg_scale, float noise_scale);
+
 /* y = a*x + b*y elementwise (IP-Adapter FaceID: out + ipa_scale * out_ipa, attention.py:681;
  * ControlNet residual adds, cldm.py:57-65) */
 int crg_axpby(crg_ctx* ctx, void* stream, const void* x, void* y, int64_t n, float a, float b, int dtype);

@@ -361,3 +361,23 @@ def test_errors_are_python_exceptions():
         ops.linear(torch.zeros(4, 16), torch.zeros(8, 16))  # CPU tensors: no fallback
     with pytest.raises(L.CrgError):
         ops.group_norm(torch.zeros(1, 36, 4, 4, device=_dev(), dtype=BF), torch.ones(36, device=_dev()), torch.zeros(36, device=_dev()), 32, 1e-5)
+
+
+def test_cfg_euler_step_matches_the_elementwise_chain():
+    """crg_cfg_euler_step == CompVisDenoiser scalings + CFG + Euler(-ancestral) update written as separate fp32 ops
+    (external.py:111-114, ldm_wrapper_for_k_diffusion.py:99, sampling.py:134-142,157-162), one rounding at a time"""
+    from cremage_amd import ops
+    b, shape = 3, (4, 16, 16)
+    x = rnd(b, *shape, seed=90).to(_dev())
+    eps = rnd(2 * b, *shape, seed=91).to(_dev())
+    noise = rnd(b, *shape, seed=92).to(_dev())
+    sigma, dt, cfg, nscale = 3.7, -0.9, 7.5, 0.35
+    for nz in (None, noise):
+        e_u, e_c = eps.chunk(2)
+        den_u, den_c = x + e_u * (-sigma), x + e_c * (-sigma)
+        den = den_u + cfg * (den_c - den_u)
+        ref = x + ((x - den) / sigma) * dt
+        if nz is not None:
+            ref = ref + nz * nscale
+        got = ops.cfg_euler_step_(x.clone(), eps, nz, sigma, dt, cfg, nscale)
+        assert (got - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
