@@ -96,6 +96,28 @@ def txt2img(ldm: LatentDiffusion, c: torch.Tensor, uc: Optional[torch.Tensor], *
 
 
 @torch.no_grad()
+def txt2img_hires(ldm: LatentDiffusion, c: torch.Tensor, uc: Optional[torch.Tensor], *, steps: int = 20, sampler: str = "euler_a",
+                  cfg_scale: float = 7.5, height: int = 512, width: int = 512, factor: float = 2.0, strength: float = 0.5,
+                  x0: Optional[torch.Tensor] = None, fwd_noise: Optional[torch.Tensor] = None, noise_sampler: Optional[Callable] = None,
+                  decode: bool = True):
+    """Hires-fix with the latent upscaler (image_generator.py:958-999): txt2img at (height, width); bilinear upscale of the final
+    latents by `factor`; forward-diffuse to t_enc = int(strength * steps) (k_diffusion_samplers.py:255-296) and denoise the last
+    t_enc + 1 sigmas at the larger size (img2img_sampling :227-246).  Returns (images, latents, base latents)."""
+    import torch.nn.functional as F
+    b = c.shape[0]
+    smp = SAMPLERS[sampler](ldm)
+    smp.noise_sampler = noise_sampler
+    base, _ = smp.sample(S=steps, conditioning=c, batch_size=b, shape=[4, height // 8, width // 8], verbose=False,
+                         unconditional_guidance_scale=cfg_scale, unconditional_conditioning=uc, x0=x0)
+    up = F.interpolate(base, scale_factor=factor, mode="bilinear", align_corners=False)
+    t_enc = int(strength * steps)
+    z_enc = smp.stochastic_encode(up, torch.tensor([t_enc] * b, device=up.device), sampling_steps=steps, noise=fwd_noise)
+    samples, _ = smp.sample(S=steps, conditioning=c, batch_size=b, shape=list(up.shape[1:]), verbose=False,
+                            unconditional_guidance_scale=cfg_scale, unconditional_conditioning=uc, x0=z_enc, denoising_steps=t_enc)
+    return (decode_images(ldm, samples) if decode else None), samples, base
+
+
+@torch.no_grad()
 def img2img(ldm: LatentDiffusion, init_image: torch.Tensor, c: torch.Tensor, uc: Optional[torch.Tensor], *, steps: int = 20,
             strength: float = 0.75, cfg_scale: float = 7.5, enc_noise: Optional[torch.Tensor] = None,
             fwd_noise: Optional[torch.Tensor] = None, decode: bool = True):

@@ -448,6 +448,43 @@ def g_trajectories():
          init_latent=init_latent, z_enc=z_enc, x=x, img=img)
 
 
+def g_hires_latent():
+    """Hires-fix, latent upscaler (image_generator.py:958-999): txt2img at the base size, F.interpolate(bilinear) of the final
+    latents, k-diffusion stochastic_encode to t_enc = int(strength * S) (k_diffusion_samplers.py:255-296) and a partial Euler
+    denoise over the last t_enc + 1 sigmas (img2img_sampling :227-246, `denoising_steps`), through the reference's sampler stack."""
+    ldm = _tiny_ldm()
+    B, L, S, factor, strength = 2, 8, 6, 2, 0.5
+    c = synth_input("hires.c", (B, 77, 96), SEED)
+    uc = synth_input("hires.uc", (B, 77, 96), SEED)
+    x0 = synth_input("hires.x0", (B, 4, L, L), SEED)
+    noise = synth_input("hires.noise", (B, 4, factor * L, factor * L), SEED)
+    R_ks.trange = R_ksamp.trange = lambda *a, **k: range(*a)
+    t_enc = int(strength * S)
+    # the constructor keeps its schedule buffers in fp32 only when cuda "is available" (k_diffusion_samplers.py:97-100; fp16
+    # otherwise) and register_buffer then moves them to "cuda" (:113-121): build it under the shim with that move neutralised,
+    # so that stochastic_encode uses the fp32 coefficients of the GPU configuration
+    orig_rb = R_ks.KDiffusionSamplerBase.register_buffer
+    R_ks.KDiffusionSamplerBase.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+    try:
+        with fp32_forward():
+            s = R_ks.EulerSampler(ldm)
+    finally:
+        R_ks.KDiffusionSamplerBase.register_buffer = orig_rb
+    assert s.sqrt_alphas_cumprod.dtype == torch.float32
+    with fp32_forward(), contextlib.redirect_stdout(open(os.devnull, "w")):
+        s._sample_common_prep(S=S, batch_size=B, shape=[4, L, L], conditioning=c, unconditional_guidance_scale=7.5,
+                              unconditional_conditioning=uc, x0=x0)
+        base, _ = s.do_sample()
+        up = torch.nn.functional.interpolate(base, scale_factor=factor, mode="bilinear", align_corners=False)
+        z_enc = s.stochastic_encode(up, torch.tensor([t_enc] * B), sampling_steps=S, noise=noise)
+        s._sample_common_prep(S=S, batch_size=B, shape=[4, factor * L, factor * L], conditioning=c, unconditional_guidance_scale=7.5,
+                              unconditional_conditioning=uc, x0=z_enc, denoising_steps=t_enc)
+        x, _ = s.do_sample()
+        img = ldm.decode_first_stage(x)
+    save("traj_hires_latent", dict(B=B, L=L, S=S, factor=factor, strength=strength, t_enc=t_enc, cfg=7.5, seed=SEED, unet=TINY_UNET, dd=TINY_DD),
+         base=base, up=up, z_enc=z_enc, sigmas=s.sigmas, x=x, img=img)
+
+
 def g_alphas_doc():
     """The reference's only numeric known-answer artefact for this path: 1000 float64 alphas_cumprod values
     printed in docs/developers/ddpm_cumprod_alpha_example_values.md (data only, no source)."""
@@ -700,7 +737,7 @@ def g_sgm_img2img():
 
 CASES = dict(alphas_doc=g_alphas_doc, param_contract=g_param_contract, groupnorm=g_groupnorm, timestep_embedding=g_timestep_embedding, resblock=g_resblock, updown=g_updown,
              attention=g_attention, transformer=g_transformer, unet_tiny=g_unet_tiny, unet_small_sd=g_unet_small_sd,
-             vae_blocks=g_vae_blocks, vae_tiny=g_vae_tiny, schedules=g_schedules, trajectories=g_trajectories)
+             vae_blocks=g_vae_blocks, vae_tiny=g_vae_tiny, schedules=g_schedules, trajectories=g_trajectories, hires_latent=g_hires_latent)
 CASES.update(controlnet_hook=g_controlnet_hook, controlnet=g_controlnet)
 CASES.update(sgm_unet_tiny=g_sgm_unet_tiny, sgm_unet_small=g_sgm_unet_small, sgm_trajectory=g_sgm_trajectory, sgm_img2img=g_sgm_img2img)
 FULL = dict(controlnet_sd15_full=g_controlnet_sd15_full, unet_sd15_full=g_unet_sd15_full, vae_sd15_full=g_vae_sd15_full, sgm_unet_full=g_sgm_unet_full)

@@ -559,6 +559,19 @@ def sample_euler(denoise, x, sigmas):
     return x
 
 
+def kdiff_stochastic_encode(x0, t_enc: int, sampling_steps: int, noise, acp=None):
+    """KDiffusionSamplerBase.stochastic_encode k_diffusion_samplers.py:255-296: DDPM index t = int(t_enc * 1000 / S);
+    x_t = sqrt(acp[t]) * x0 + sqrt(1 - acp[t]) * noise."""
+    acp = alphas_cumprod().float() if acp is None else acp
+    t = int(t_enc * 1000.0 / sampling_steps)
+    return acp[t].sqrt() * x0 + (1.0 - acp[t]).sqrt() * noise
+
+
+def hires_latent_upscale(samples, factor):
+    """image_generator.py:975: F.interpolate(samples, scale_factor, mode='bilinear', align_corners=False) in latent space."""
+    return F.interpolate(samples, scale_factor=factor, mode="bilinear", align_corners=False)
+
+
 def get_ancestral_step(sigma_from, sigma_to, eta: float = 1.0):
     """k_diffusion/sampling.py:51-58."""
     if not eta:

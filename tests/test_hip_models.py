@@ -257,6 +257,23 @@ def test_trajectory(nm):
     assert (images.cpu() - ref_img).abs().max().item() < 2e-3
 
 
+def test_trajectory_hires_latent():
+    """Hires-fix with the latent upscaler (image_generator.py:958-999) vs the reference's sampler stack"""
+    from cremage_amd import pipeline as P
+    meta, g = load_golden("traj_hires_latent")
+    ldm = P.build_synthetic_ldm(meta["unet"], meta["dd"], DEV, unet_dtype=torch.float32, vae_dtype=torch.float32, seed=meta["seed"])
+    B, L, seed, f = meta["B"], meta["L"], meta["seed"], meta["factor"]
+    c, uc = synth_input("hires.c", (B, 77, 96), seed).to(DEV), synth_input("hires.uc", (B, 77, 96), seed).to(DEV)
+    x0 = synth_input("hires.x0", (B, 4, L, L), seed).to(DEV)
+    noise = synth_input("hires.noise", (B, 4, f * L, f * L), seed).to(DEV)
+    images, x, base = P.txt2img_hires(ldm, c, uc, steps=meta["S"], sampler="euler", cfg_scale=meta["cfg"], height=8 * L, width=8 * L,
+                                      factor=f, strength=meta["strength"], x0=x0, fwd_noise=noise)
+    close(base, g["base"], 2e-3, "hires base latent")
+    close(x, g["x"], 3e-3, "hires latent")
+    ref_img = ((g["img"] + 1) / 2).clamp(0, 1)
+    assert (images.cpu() - ref_img).abs().max().item() < 3e-3
+
+
 def test_trajectory_ddim_img2img():
     from cremage_amd import pipeline as P
     meta, g = load_golden("traj_ddim_img2img")

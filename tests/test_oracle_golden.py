@@ -190,6 +190,31 @@ def test_trajectory(nm):
     assert max_abs(img, g["img"]) < 2e-3
 
 
+def test_trajectory_hires_latent():
+    """hires-fix latent path: base Euler trajectory, bilinear latent upscale, k-diffusion stochastic_encode, partial denoise"""
+    meta, g = load_golden("traj_hires_latent")
+    usd, vsd = _tiny_models(meta)
+    B, L, S, seed = meta["B"], meta["L"], meta["S"], meta["seed"]
+    c, uc = synth_input("hires.c", (B, 77, 96), seed), synth_input("hires.uc", (B, 77, 96), seed)
+    x0 = synth_input("hires.x0", (B, 4, L, L), seed)
+    noise = synth_input("hires.noise", (B, 4, meta["factor"] * L, meta["factor"] * L), seed)
+    sig_tab = R.sigmas_table(R.alphas_cumprod().float())
+    sigmas = R.get_sigmas(sig_tab, S)
+    eps = lambda x, t, ctx: R.unet_forward(usd, meta["unet"], x, t, ctx)
+    den = lambda x, s: R.cfg_denoise(eps, sig_tab, x, s, c, uc, meta["cfg"])
+    base = R.sample_euler(den, x0, sigmas)
+    assert max_abs(base, g["base"]) < 2e-3
+    up = R.hires_latent_upscale(base, meta["factor"])
+    assert max_abs(up, g["up"]) < 2e-3
+    z_enc = R.kdiff_stochastic_encode(up, meta["t_enc"], S, noise)
+    assert max_abs(z_enc, g["z_enc"]) < 2e-3
+    part = sigmas[-(meta["t_enc"] + 1):]
+    assert max_abs(part, g["sigmas"]) < 1e-6
+    x = R.sample_euler(den, z_enc, part)
+    assert max_abs(x, g["x"]) < 3e-3
+    assert max_abs(R.decode_first_stage(vsd, meta["dd"], x), g["img"]) < 3e-3
+
+
 def test_trajectory_ddim_img2img():
     meta, g = load_golden("traj_ddim_img2img")
     usd, vsd = _tiny_models(meta)
