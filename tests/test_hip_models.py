@@ -483,6 +483,31 @@ def test_controlnet_sd15_full():
     close(eps, g["eps"], TOL_NET[BF], "eps")
 
 
+def test_reference_gpu_calling_convention_half_autocast():
+    """The reference's GPU flow (image_generator.py:489-493, :748-751): `model.half()` then `torch.autocast` around a sampler
+    that feeds fp32 latents.  The drop-in must take fp16 PARAMETERS (packed to bf16 images), run its bf16 path, return x.dtype
+    (openaimodel.py:810), and agree with the reference's fp32 output to the bf16 tolerance; same for the VAE decode."""
+    from cremage_amd.ldm_hip.unet import UNetModel
+    from cremage_amd.ldm_hip.vae import AutoencoderKL
+    meta, g = load_golden("unet_tiny")
+    cfg = meta["cfg"]
+    m = synth_fill_(UNetModel(**cfg), meta["seed"], prefix=meta["prefix"]).half().to(DEV).eval()
+    assert next(m.parameters()).dtype == torch.float16
+    x = synth_input("unet_tiny.x", (meta["B"], 4, meta["L"], meta["L"]), meta["seed"]).to(DEV)
+    ctx = synth_input("unet_tiny.ctx", (meta["B"], meta["m"], cfg["context_dim"]), meta["seed"]).to(DEV)
+    with torch.no_grad(), torch.autocast(device_type="cuda"):
+        y = m(x, timesteps=g["t"].to(DEV), context=ctx)
+    assert y.dtype == torch.float32
+    close(y, g["y"], TOL_NET[BF], "unet half+autocast")
+    vm, vg = load_golden("vae_tiny")
+    vae = synth_fill_(AutoencoderKL(vm["dd"], None, 4), vm["seed"], prefix="vae.").half().to(DEV).eval()
+    z = synth_input("vae_tiny.z", (2, 4, 8, 8), vm["seed"]).to(DEV)
+    with torch.no_grad(), torch.autocast(device_type="cuda"):
+        dec = vae.decode(z)
+    assert dec.dtype == torch.float32 and torch.isfinite(dec).all()
+    close(dec, vg["dec"], TOL_NET[BF], "vae half+autocast")
+
+
 def test_c4_unit_img2img_768_properties():
     """BASELINE.json configs[3]'s per-GPU unit at full size (SD1.5 img2img 768x768, 2 images, DDIM, strength 0.75 ->
     t_enc = 15 of 20 steps, VAE encode + decode) through size-independent properties: determinism (bitwise), and
