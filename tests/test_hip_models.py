@@ -115,6 +115,39 @@ def test_cross_attention_lora_ipa(dtype):
     close(y, g["y"], TOL_BLOCK[dtype], tag)
 
 
+def test_weight_updates_after_first_forward_are_seen():
+    """The reference mutates a LIVE model: LoRA injection replaces parameters with `setattr(submodule, name, nn.Parameter(...))`
+    (image_generator.py:408-453) and checkpoints arrive through `load_state_dict` (:345), both possibly after the model has
+    already run.  Packed weights, LoRA merges and the fused Q|K weight are caches keyed on tensor identity + version, so the
+    next forward must see the new values (and must equal a freshly built module holding them)."""
+    import torch.nn as nn
+    from cremage_amd.ldm_hip.transformer import CrossAttention
+    mk = lambda: CrossAttention(128, None, heads=4, dim_head=32, lora_ranks=[4], lora_weights=[0.7])
+    m = synth_fill_(mk(), 5, prefix="upd.").to(BF).to(DEV).eval()
+    x = synth_input("upd.x", (2, 64, 128), 5).to(DEV).to(BF)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if "_lora_" in name and p.ndim > 0:
+                p.copy_(synth_input("upd." + name, p.shape, 5, 0.2).to(p.dtype))
+        y0 = m(x).float().cpu()
+        # 1. LoRA injection the reference's way: a NEW Parameter object under the same name
+        new_down = nn.Parameter(synth_input("upd.new_down", m.q_lora_downs[0].weight.shape, 6, 0.3).to(BF).to(DEV))
+        setattr(m.q_lora_downs[0], "weight", new_down)
+        y1 = m(x).float().cpu()
+        assert rel_l2(y1, y0) > 1e-3
+        # 2. a checkpoint loaded into the live module (in-place copy_: version bump, same identity)
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        sd["to_v.weight"] = synth_input("upd.new_v", sd["to_v.weight"].shape, 7, 0.1).to(BF).to(DEV)
+        sd["to_k.weight"] = synth_input("upd.new_k", sd["to_k.weight"].shape, 7, 0.1).to(BF).to(DEV)
+        m.load_state_dict(sd)
+        y2 = m(x).float().cpu()
+        assert rel_l2(y2, y1) > 1e-3
+        fresh = mk().to(BF).to(DEV).eval()
+        fresh.load_state_dict(sd)
+        y3 = fresh(x).float().cpu()
+    assert torch.equal(y2, y3)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, BF])
 def test_transformer_blocks(dtype):
     from cremage_amd.ldm_hip.transformer import BasicTransformerBlock, FeedForward, SpatialTransformer
