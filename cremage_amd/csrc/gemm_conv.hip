@@ -37,6 +37,9 @@ struct GemmP {
   int cm;  // conv K order: 0 = tap-major [tap][Cin]; 1 = chunk-major [Cin/64][tap][64] (consecutive k-tiles re-read the
            // same 64-channel slab of neighbouring pixels -> the 9 taps hit in L1 instead of going back to L2)
   int tiles_n, tiles_m;
+  // partial launches (tail of a grid that does not fill whole rounds, see launch()): tiles [tile_base, tile_base + tile_count)
+  // of the n-fastest tile order; the split-K slab then only holds rows >= slab_row0
+  int tile_base, tile_count, slab_row0;
   int xg_m, xg_n, xg_s;  // XCD partition of the (m-tile, n-tile, k-slice) grid, product 8; xg_s == 0: legacy contiguous order
 };
 
@@ -62,11 +65,11 @@ __device__ __forceinline__ void block_to_tile(const GemmP& p, int& tile_m, int& 
     tile_m = xm * nml + tm;
     sid = xs * nsl + ts;
   } else {  // tile counts not divisible: contiguous runs of tiles per XCD (bijective for any count)
-    const int T = p.tiles_n * p.tiles_m;
+    const int T = p.tile_count;
     sid = L / T;
     int bid = L - sid * T;
     const int q = T >> 3, r = T & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3) + p.tile_base;
     tile_n = bid % p.tiles_n;
     tile_m = bid / p.tiles_n;
   }
@@ -92,7 +95,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][
                                               int bz, int sid, const bf16x4 (&pre)[WNT][WMT], bool use_pre,
                                               const f32x4 (&bpre)[WNT], bool use_bpre) {
   if (p.splits > 1) {
-    float* S = p.slab + ((long)bz * p.splits + sid) * p.M * p.N;
+    const long srows = p.M - p.slab_row0;
+    float* S = p.slab + ((long)bz * p.splits + sid) * srows * p.N - (long)p.slab_row0 * p.N;
 #pragma unroll
     for (int j = 0; j < WMT; ++j) {
       const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
@@ -721,16 +725,18 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
 template <typename YT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p) {
   const int n4 = p.N >> 2;
-  const long total = (long)p.M * n4;
+  const long srows = p.M - p.slab_row0;
+  const long total = srows * n4;
   const int bz = blockIdx.y;
-  const float* S = p.slab + (long)bz * p.splits * p.M * p.N;
+  const float* S = p.slab + (long)bz * p.splits * srows * p.N - (long)p.slab_row0 * p.N;
   YT* Y = reinterpret_cast<YT*>(p.y) + (long)bz * p.y_bs;
   const YT* R = p.res ? reinterpret_cast<const YT*>(p.res) + (long)bz * p.r_bs : nullptr;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int m = (int)(idx / n4);
-    const int n = (int)(idx - (long)m * n4) * 4;
+    const int mr = (int)(idx / n4);
+    const int m = mr + p.slab_row0;
+    const int n = (int)(idx - (long)mr * n4) * 4;
     f32x4 v = *reinterpret_cast<const f32x4*>(S + (long)m * p.N + n);
-    for (int s = 1; s < p.splits; ++s) v += *reinterpret_cast<const f32x4*>(S + ((long)s * p.M + m) * p.N + n);
+    for (int s = 1; s < p.splits; ++s) v += *reinterpret_cast<const f32x4*>(S + ((long)s * srows + m) * p.N + n);
     if (p.bias_mode == CRG_BIAS_COL) v += *reinterpret_cast<const f32x4*>(p.bias + n);
     else if (p.bias_mode == CRG_BIAS_ROW) v += p.bias[m];
     if (p.epi == CRG_EPI_SILU) {
@@ -772,7 +778,22 @@ inline int choose_splits(const GemmP& p, int tiles, int batch) {
   // K = 2560 GEMMs lose 5 %, hence the nk bound)
   // short K (nk < 24) is not split: measured slower than the 64-row / 8-wave configuration on the unsplit problem
   if (blocks >= 512 || nk < 24 || (blocks >= 256 && nk < 64)) return 1;
-  int s = (int)((512 + blocks - 1) / blocks);
+  int s;
+  if (blocks >= 256) {
+    // one to two blocks per CU and a long K: among 2..4 slices take the one whose blocks fill whole rounds of 512 best
+    // (256 tiles -> 2, 288 tiles (768x768 latents at the 48x48 level) -> 3, 384 -> 4); ties go to fewer slices
+    s = 2;
+    double best = 1e9;
+    for (int c = 2; c <= 4; ++c) {
+      const double t = (double)((blocks * c + 511) / 512) / c;
+      if (t < best - 1e-9) {
+        best = t;
+        s = c;
+      }
+    }
+    return s;
+  }
+  s = (int)((512 + blocks - 1) / blocks);
   if (s > nk / 8) s = nk / 8;
   if (s > 16) s = 16;
   return s < 2 ? 1 : s;
@@ -815,7 +836,7 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", lds, hipGetErrorString(e));
     attr_set = true;
   }
-  dim3 grid(p.tiles_n * p.tiles_m * p.splits, batch, 1);
+  dim3 grid(p.tile_count * p.splits, batch, 1);
   constexpr int slot = !GLDS ? (CONV ? CRG_K_CONV_X3 : CRG_K_GEMM_X3)
                              : (CONV ? (WNT == 5 ? CRG_K_CONV_W5 : WNT == 4 ? CRG_K_CONV_W4 : CRG_K_CONV_W1)
                                      : (WNT == 5 ? CRG_K_GEMM_W5 : WNT == 4 ? CRG_K_GEMM_W4 : CRG_K_GEMM_W1));
@@ -860,8 +881,45 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     if (!p.slab) return crg_fail(ctx, -12, "gemm: out of scratch for %d split-K slabs", p.splits);
   }
   choose_xcd_partition(p, wk);
+  p.tile_base = 0;
+  p.tile_count = p.tiles_n * p.tiles_m;
+  p.slab_row0 = 0;
   int rc;
   if constexpr (GLDS) {
+    // Tail split: with two blocks per CU a grid runs in rounds of 512 blocks; T = 512 k + r with a small r costs a whole extra
+    // round for r blocks (768x768 latents: 576 tiles -> the second round is 1/8 full and the conv runs at 56 % of its rate).
+    // The first 512 k tiles go out as they are; the last r tiles - whole rows of m-tiles - are cut along K so that they
+    // fill the chip once more for a fraction of a round, and are summed by the split-K reduce over just their rows.
+    const int T = p.tile_count, nk = (p.K + BK - 1) / BK;
+    const int r = T % 512, T1 = T - r;
+    if (cfg == 1 && p.splits == 1 && batch == 1 && T1 >= 512 && r > 0 && r <= 224 && nk >= 16 && r % p.tiles_n == 0 &&
+        p.epi != CRG_EPI_GEGLU && !(p.N & 3)) {
+      int s2 = 512 / r;
+      if (s2 > nk / 4) s2 = nk / 4;
+      if (s2 > 8) s2 = 8;
+      if (s2 >= 2) {
+        const int row0 = (T1 / p.tiles_n) * 128;
+        float* slab = (float*)crg_scratch(ctx, (size_t)s2 * (p.M - row0) * p.N * sizeof(float));
+        if (!slab) return crg_fail(ctx, -12, "gemm: out of scratch for the tail slab");
+        p.xg_s = 0;  // partial ranges use the contiguous-run order
+        p.tile_count = T1;
+        rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 2, 4, 1>(ctx, st, p, batch, Work{wk.flops * T1 / T, wk.bytes * T1 / T, 0, 0});
+        if (rc) return rc;
+        p.tile_base = T1;
+        p.tile_count = r;
+        p.splits = s2;
+        p.slab = slab;
+        p.slab_row0 = row0;
+        rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 2, 4, 1>(ctx, st, p, batch, Work{wk.flops * r / T, wk.bytes * r / T, 0, 0});
+        if (rc) return rc;
+        const long total4 = (long)(p.M - row0) * (p.N >> 2);
+        const int rg = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+        crg_prof_scope ps(ctx, st, CRG_K_SPLITK, (double)s2 * (p.M - row0) * p.N, (double)(p.M - row0) * p.N * (4.0 * s2 + sizeof(YT)));
+        hipLaunchKernelGGL(splitk_reduce_kernel<YT>, dim3(rg, 1), dim3(256), 0, st, p);
+        CRG_CHECK_LAUNCH(ctx, "splitk_reduce(tail)");
+        return 0;
+      }
+    }
     if (cfg == 3) rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 4, 2, 2>(ctx, st, p, batch, wk);
     else if (cfg == 4) rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 2, 2, 1>(ctx, st, p, batch, wk);
     else rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 2, 4, 1>(ctx, st, p, batch, wk);
@@ -895,6 +953,9 @@ int launch_planes(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     if (!p.slab) return crg_fail(ctx, -12, "gemm: out of scratch for %d split-K slabs", p.splits);
   }
   choose_xcd_partition(p, wk);
+  p.tile_base = 0;
+  p.tile_count = p.tiles_n * p.tiles_m;
+  p.slab_row0 = 0;
   void (*kern)(GemmP) = gemm_glds_kernel<WNT, float, CONV, 2, 4, 2, 2>;
   static bool attr_set = false;
   if (!attr_set) {

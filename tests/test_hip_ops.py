@@ -61,7 +61,8 @@ DTYPES = [BF, torch.float32]
                                    (3000, 1280, 320),   # 192 tiles, short K          -> D (64-row tiles, 4 waves)
                                    (8200, 1280, 136),   # 520 tiles                   -> A (4 waves, 2 blocks per CU)
                                    (2048, 640, 1280),   # 64 tiles, short K           -> C (64-row tiles, 8 waves)
-                                   (520, 320, 4096)])   # 10 tiles, long K            -> A + split-K
+                                   (520, 320, 4096),    # 10 tiles, long K            -> A + split-K
+                                   (35840, 320, 1024)]) # 560 tiles = 512 + 48        -> A + tail split (48 tiles cut along K)
 def test_linear_shapes(dtype, M, N, K):
     from cremage_amd import ops
     x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
@@ -161,7 +162,7 @@ def test_conv2d(dtype, case):
     check(got, ref, dtype, "conv " + case)
 
 
-@pytest.mark.parametrize("N,C,Co,hw", [(2, 64, 320, 96), (4, 64, 320, 128), (1, 64, 640, 40)])
+@pytest.mark.parametrize("N,C,Co,hw", [(2, 64, 320, 96), (4, 64, 320, 128), (1, 64, 640, 40), (4, 128, 320, 96)])  # last: 576 tiles -> tail split
 def test_conv2d_tile_configs(N, C, Co, hw):
     """bf16 3x3 convs sized to land on configurations D (288 tiles of 128 rows), A (1024 blocks) and C (26 tiles of 128 rows)."""
     from cremage_amd import ops
