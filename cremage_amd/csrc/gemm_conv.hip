@@ -40,6 +40,7 @@ struct GemmP {
   // partial launches (tail of a grid that does not fill whole rounds, see launch()): tiles [tile_base, tile_base + tile_count)
   // of the n-fastest tile order; the split-K slab then only holds rows >= slab_row0
   int tile_base, tile_count, slab_row0;
+  int ks_q, ks_r;  // k-tiles per K-slice: nk_total = splits * ks_q + ks_r
   int xg_m, xg_n, xg_s;  // XCD partition of the (m-tile, n-tile, k-slice) grid, product 8; xg_s == 0: legacy contiguous order
 };
 
@@ -365,9 +366,10 @@ __global__ __launch_bounds__(256 * KG) void gemm_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk_total = (p.K + BK - 1) / BK;
-  const int kt_begin = (int)((long)nk_total * sid / p.splits);
-  const int nk = (int)((long)nk_total * (sid + 1) / p.splits);
+  // k-tile range of this K-slice: the first ks_r slices take ks_q + 1 tiles, the others ks_q (ks_q, ks_r from the host - a
+  // 64-bit division by the runtime split count here cost ~1 us of scalar work on every block's latency chain)
+  const int kt_begin = sid * p.ks_q + (sid < p.ks_r ? sid : p.ks_r);
+  const int nk = kt_begin + p.ks_q + (sid < p.ks_r ? 1 : 0);
   load_tile(kt_begin);
   store_tile(kt_begin & 1);
   __syncthreads();
@@ -527,9 +529,10 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
     wrow_off[q] = (long)n * p.ldw;
   }
 
-  const int nk_total = (p.K + BK - 1) / BK;
-  const int kt_begin = (int)((long)nk_total * sid / p.splits);
-  const int nk = (int)((long)nk_total * (sid + 1) / p.splits);
+  // k-tile range of this K-slice: the first ks_r slices take ks_q + 1 tiles, the others ks_q (ks_q, ks_r from the host - a
+  // 64-bit division by the runtime split count here cost ~1 us of scalar work on every block's latency chain)
+  const int kt_begin = sid * p.ks_q + (sid < p.ks_r ? sid : p.ks_r);
+  const int nk = kt_begin + p.ks_q + (sid < p.ks_r ? 1 : 0);
 
   // running (tap, channel) of this lane's logical chunk; advanced by 64 channels per k-tile
   int kc = kt_begin * BK + clog * 8;
@@ -836,6 +839,11 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", lds, hipGetErrorString(e));
     attr_set = true;
   }
+  {
+    const int nk_total = (p.K + BK - 1) / BK;
+    p.ks_q = nk_total / p.splits;
+    p.ks_r = nk_total % p.splits;
+  }
   dim3 grid(p.tile_count * p.splits, batch, 1);
   constexpr int slot = !GLDS ? (CONV ? CRG_K_CONV_X3 : CRG_K_GEMM_X3)
                              : (CONV ? (WNT == 5 ? CRG_K_CONV_W5 : WNT == 4 ? CRG_K_CONV_W4 : CRG_K_CONV_W1)
@@ -964,6 +972,9 @@ int launch_planes(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     attr_set = true;
   }
   {
+    const int nk_total = (p.K + BK - 1) / BK;
+    p.ks_q = nk_total / p.splits;
+    p.ks_r = nk_total % p.splits;
     crg_prof_scope ps(ctx, st, CONV ? CRG_K_CONV_X3 : CRG_K_GEMM_X3, wk.flops, wk.bytes);
     hipLaunchKernelGGL(kern, dim3(p.tiles_n * p.tiles_m * p.splits, batch, 1), dim3(512), lds, st, p);
     CRG_CHECK_LAUNCH(ctx, "gemm(planes)");
