@@ -40,6 +40,7 @@ struct GemmP {
   // partial launches (tail of a grid that does not fill whole rounds, see launch()): tiles [tile_base, tile_base + tile_count)
   // of the n-fastest tile order; the split-K slab then only holds rows >= slab_row0
   int tile_base, tile_count, slab_row0;
+  int pair;        // paired-column output mapping (see unpair_col): 16-byte epilogue accesses
   int ks_q, ks_r;  // k-tiles per K-slice: nk_total = splits * ks_q + ks_r
   int xg_m, xg_n, xg_s;  // XCD partition of the (m-tile, n-tile, k-slice) grid, product 8; xg_s == 0: legacy contiguous order
 };
@@ -202,6 +203,84 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][
           if (R) s += (float)R[(long)m * p.ldr + n + e];
           Y[(long)m * p.ldy + n + e] = (YT)s;
         }
+      }
+    }
+  }
+}
+
+// ---- paired output columns -------------------------------------------------------------------------------------------
+// The weight tile is the MFMA A operand, so WHICH output column sits on MFMA row r of tile i is decided by the order of the
+// weight rows in LDS.  With the natural order a lane owns columns 16 i + 4 fq .. +3 of every tile: 8-byte accesses, 16
+// different cache lines per wave-instruction - and the loads of the residual / the stores of the result, not the MFMAs,
+// were what a short-K block spent its time on (in-kernel stamps: 2-5 us of a 13-16 us block).  Storing the rows of each
+// PAIR of tiles (2u, 2u+1) as  row(t, rho) <- column 32 u + 8 (rho >> 2) + 4 t + (rho & 3)  makes the lane's two 4-column
+// groups adjacent (columns 32 u + 8 fq .. +7): one 16-byte access where there were two 8-byte ones.  The permutation is
+// applied once, to the per-lane source row of the LDS-DMA; the fragment reads and the MFMAs are unchanged.
+template <int WNT>
+__device__ __forceinline__ int unpair_col(int pos) {  // LDS row position within the weight tile -> output column within the tile
+  const int w = pos / (16 * WNT);                       // which wave column (wn) the row belongs to
+  const int l = pos - w * (16 * WNT);                   // position inside that wave's 16*WNT rows
+  if (l >= 32 * (WNT / 2)) return pos;                  // unpaired last tile (odd WNT)
+  const int g = l >> 5, t = (l >> 4) & 1, rho = l & 15;
+  return w * (16 * WNT) + 32 * g + 8 * (rho >> 2) + 4 * t + (rho & 3);
+}
+
+// rres[i][j] / bpre[i]: residual and bias of this lane in the paired mapping (tile i of a pair holds columns +4 (i & 1)),
+// fetched ahead of the K loop into the same registers the unpaired mapping uses.
+template <int WNT, int WMT>
+__device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)[WNT][WMT], int m0, int n0, int wm, int wn, int frow,
+                                                    int fq, int bz, const bf16x4 (&rres)[WNT][WMT], bool has_res,
+                                                    const f32x4 (&bpre)[WNT], bool has_bias) {
+  bf16* Y = reinterpret_cast<bf16*>(p.y) + (long)bz * p.y_bs;
+  const int nb = n0 + wn * (16 * WNT);
+#pragma unroll
+  for (int j = 0; j < WMT; ++j) {
+    const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
+    if (m >= p.M) continue;
+    const float brow = (p.bias_mode == CRG_BIAS_ROW) ? p.bias[m] : 0.f;
+    const float* cv = p.cvec ? p.cvec + (long)(m / p.cvec_rows) * p.cvec_ld : nullptr;
+    auto finish = [&](f32x4 v, int i, int n) {
+      if (has_bias) v += bpre[i];
+      else if (p.bias_mode == CRG_BIAS_ROW) v += brow;
+      if (p.epi == CRG_EPI_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = crg_silu_f(v[e]);
+      }
+      if (cv) v += *reinterpret_cast<const f32x4*>(cv + n);
+      return v;
+    };
+#pragma unroll
+    for (int u = 0; u < WNT / 2; ++u) {
+      const int n = nb + 32 * u + 8 * fq;
+      if (n >= p.N) continue;  // N % 8 == 0 in this mode: a group is in or out as a whole
+      f32x4 a = finish(acc[2 * u][j], 2 * u, n), b = finish(acc[2 * u + 1][j], 2 * u + 1, n + 4);
+      if (has_res) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] += (float)rres[2 * u][j][e];
+          b[e] += (float)rres[2 * u + 1][j][e];
+        }
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (bf16)a[e];
+        o[4 + e] = (bf16)b[e];
+      }
+      *reinterpret_cast<bf16x8*>(Y + (long)m * p.ldy + n) = o;
+    }
+    if constexpr (WNT & 1) {
+      const int n = nb + 16 * (WNT - 1) + 4 * fq;
+      if (n < p.N) {
+        f32x4 a = finish(acc[WNT - 1][j], WNT - 1, n);
+        if (has_res) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] += (float)rres[WNT - 1][j][e];
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)a[e];
+        *reinterpret_cast<bf16x4*>(Y + (long)m * p.ldy + n) = o;
       }
     }
   }
@@ -524,7 +603,8 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
   long wrow_off[WL];
 #pragma unroll
   for (int q = 0; q < WL; ++q) {
-    const int n = n0 + (wave + NW * q) * 8 + rsub;
+    const int pos = (wave + NW * q) * 8 + rsub;                     // LDS row of the weight tile this lane stages
+    const int n = n0 + (p.pair ? unpair_col<WNT>(pos) : pos);     // the output column (= weight row) that lives there
     wok[q] = n < p.N && (wave + NW * q) < WRG;
     wrow_off[q] = (long)n * p.ldw;
   }
@@ -629,29 +709,63 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
   // residual tile of this lane, fetched first so that its latency hides under the whole K loop (bf16 outputs); being the
   // oldest loads in flight they are retired by the first counted wait
   bf16x4 rres[WNT][WMT];
+  f32x4 bpre[WNT];
+  bool pair_res = false, pair_bias = false;
   const bool pre_res = sizeof(YT) == 2 && p.res && p.splits == 1 && (p.ldr & 3) == 0 && p.epi != CRG_EPI_GEGLU;
-  if (pre_res && kg == 0) {
-    const bf16* R = reinterpret_cast<const bf16*>(p.res) + (long)bz * p.r_bs;
+  const bool pre_bias = p.bias_mode == CRG_BIAS_COL && p.splits == 1 && p.epi != CRG_EPI_GEGLU;
+  if (p.pair) {
+    // paired mapping (host guarantees bf16 output, N % 8 == 0, 16-byte aligned rows of y / residual, no split-K, no GEGLU)
+    pair_res = p.res != nullptr;
+    pair_bias = p.bias_mode == CRG_BIAS_COL;
+    if (kg == 0) {
+      const int nb = n0 + wn * (16 * WNT);
+      if (pair_res) {
+        const bf16* R = reinterpret_cast<const bf16*>(p.res) + (long)bz * p.r_bs;
 #pragma unroll
-    for (int j = 0; j < WMT; ++j) {
-      const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
+        for (int j = 0; j < WMT; ++j) {
+          const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
+#pragma unroll
+          for (int u = 0; u < WNT / 2; ++u) {
+            const int n = nb + 32 * u + 8 * fq;
+            const bf16x8 r8 = (m < p.M && n < p.N) ? *reinterpret_cast<const bf16x8*>(R + (long)m * p.ldr + n) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            rres[2 * u][j] = bf16x4{r8[0], r8[1], r8[2], r8[3]};
+            rres[2 * u + 1][j] = bf16x4{r8[4], r8[5], r8[6], r8[7]};
+          }
+          if constexpr (WNT & 1) {
+            const int n = nb + 16 * (WNT - 1) + 4 * fq;
+            rres[WNT - 1][j] = (m < p.M && n < p.N) ? *reinterpret_cast<const bf16x4*>(R + (long)m * p.ldr + n) : bf16x4{0, 0, 0, 0};
+          }
+        }
+      }
+      if (pair_bias) {
+#pragma unroll
+        for (int i = 0; i < WNT; ++i) {
+          const int n = (i < 2 * (WNT / 2)) ? nb + 32 * (i >> 1) + 8 * fq + 4 * (i & 1) : nb + 16 * i + 4 * fq;
+          bpre[i] = n < p.N ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+  } else {
+    if (pre_res && kg == 0) {
+      const bf16* R = reinterpret_cast<const bf16*>(p.res) + (long)bz * p.r_bs;
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) {
+        const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
+#pragma unroll
+        for (int i = 0; i < WNT; ++i) {
+          const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
+          rres[i][j] = (m < p.M && n + 4 <= p.N) ? *reinterpret_cast<const bf16x4*>(R + (long)m * p.ldr + n) : bf16x4{0, 0, 0, 0};
+        }
+      }
+    }
+    // column bias of this lane's 4-wide output groups: also fetched ahead of the K loop (a lone block per CU would otherwise
+    // pay a full global-load latency between its last MFMA and its first store)
+    if (pre_bias && kg == 0) {
 #pragma unroll
       for (int i = 0; i < WNT; ++i) {
         const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
-        rres[i][j] = (m < p.M && n + 4 <= p.N) ? *reinterpret_cast<const bf16x4*>(R + (long)m * p.ldr + n) : bf16x4{0, 0, 0, 0};
+        bpre[i] = n + 4 <= p.N ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
-    }
-  }
-
-  // column bias of this lane's 4-wide output groups: also fetched ahead of the K loop (a lone block per CU would otherwise
-  // pay a full global-load latency between its last MFMA and its first store)
-  f32x4 bpre[WNT];
-  const bool pre_bias = p.bias_mode == CRG_BIAS_COL && p.splits == 1 && p.epi != CRG_EPI_GEGLU;
-  if (pre_bias && kg == 0) {
-#pragma unroll
-    for (int i = 0; i < WNT; ++i) {
-      const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
-      bpre[i] = n + 4 <= p.N ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
 
@@ -720,6 +834,12 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
     for (int i = 0; i < WNT; ++i)
 #pragma unroll
       for (int j = 0; j < WMT; ++j) acc[i][j] += red[(i * WMT + j) * 64];
+  }
+  if constexpr (sizeof(YT) == 2 && NS == 1) {
+    if (p.pair) {
+      gemm_epilogue_pairs<WNT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, bz, rres, pair_res, bpre, pair_bias);
+      return;
+    }
   }
   gemm_epilogue<WNT, YT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid, rres, pre_res, bpre, pre_bias);
 }
@@ -844,6 +964,11 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     p.ks_q = nk_total / p.splits;
     p.ks_r = nk_total % p.splits;
   }
+  static const bool pair_on = !(getenv("CRG_PAIR") && atoi(getenv("CRG_PAIR")) == 0);  // dev knob for A/B runs
+  p.pair = (pair_on && GLDS && sizeof(YT) == 2 && p.splits == 1 && p.epi != CRG_EPI_GEGLU && (p.N & 7) == 0 && (p.ldy & 7) == 0 &&
+            (p.y_bs & 7) == 0 && ((uintptr_t)p.y & 15) == 0 &&
+            (!p.res || ((p.ldr & 7) == 0 && (p.r_bs & 7) == 0 && ((uintptr_t)p.res & 15) == 0)) &&
+            (!p.cvec || (p.cvec_ld & 3) == 0)) ? 1 : 0;
   dim3 grid(p.tile_count * p.splits, batch, 1);
   constexpr int slot = !GLDS ? (CONV ? CRG_K_CONV_X3 : CRG_K_GEMM_X3)
                              : (CONV ? (WNT == 5 ? CRG_K_CONV_W5 : WNT == 4 ? CRG_K_CONV_W4 : CRG_K_CONV_W1)
@@ -975,6 +1100,7 @@ int launch_planes(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     const int nk_total = (p.K + BK - 1) / BK;
     p.ks_q = nk_total / p.splits;
     p.ks_r = nk_total % p.splits;
+    p.pair = 0;
     crg_prof_scope ps(ctx, st, CONV ? CRG_K_CONV_X3 : CRG_K_GEMM_X3, wk.flops, wk.bytes);
     hipLaunchKernelGGL(kern, dim3(p.tiles_n * p.tiles_m * p.splits, batch, 1), dim3(512), lds, st, p);
     CRG_CHECK_LAUNCH(ctx, "gemm(planes)");

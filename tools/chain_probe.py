@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Dev probe (needs a library built with in-kernel wall_clock64 stamps, tools/ab/libcrg_timing.so): where a lone GEMM block
 spends its fixed latency chain.  Stamps: 0 kernel entry, 1 before the first DMA issue, 2 after it, 3 first tile landed (+barrier),
-4 K loop done, 5 epilogue stores retired, 6 after block_to_tile, 7 after the row descriptors."""
+4 K loop done, 5 epilogue stores retired, 6 epilogue stores issued, 7 after block_to_tile."""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cremage_amd import ops, _lib as L
@@ -23,5 +23,5 @@ for (m, n, k) in [(2048, 1280, 1280), (8192, 640, 640), (32768, 320, 320), (2048
     ts = torch.tensor(list(buf), dtype=torch.float64).reshape(nb, 8)[:, :8]
     t0 = ts[:, 0].min()
     d = (ts - ts[:, :1]) / 100.0   # wall_clock64 ticks at 100 MHz -> us
-    print(f"{(m, n, k)}: per-block median us since entry: " + "  ".join(f"s{i}={d[:, i].median().item():.2f}" for i in (6, 7, 1, 2, 3, 4, 5)) +
+    print(f"{(m, n, k)}: per-block median us since entry: " + "  ".join(f"s{i}={d[:, i].median().item():.2f}" for i in (7, 1, 2, 3, 4, 6, 5)) +
           f" | block entry spread {((ts[:, 0].max() - t0) / 100.0).item():.2f} us, last stamp {((ts[:, 5].max() - t0) / 100.0).item():.2f} us")
