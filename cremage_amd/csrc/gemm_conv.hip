@@ -225,12 +225,12 @@ __device__ __forceinline__ int unpair_col(int pos) {  // LDS row position within
   return w * (16 * WNT) + 32 * g + 8 * (rho >> 2) + 4 * t + (rho & 3);
 }
 
-// rres[i][j] / bpre[i]: residual and bias of this lane in the paired mapping (tile i of a pair holds columns +4 (i & 1)),
-// fetched ahead of the K loop into the same registers the unpaired mapping uses.
+// r2[u][j] / r1[j] / bpre[i]: residual (16 bytes per tile pair, 8 for an odd last tile) and bias of this lane in the paired
+// mapping, fetched ahead of the K loop (has_res / has_bias say whether they were).
 template <int WNT, int WMT>
 __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)[WNT][WMT], int m0, int n0, int wm, int wn, int frow,
-                                                    int fq, int bz, const bf16x4 (&rres)[WNT][WMT], bool has_res,
-                                                    const f32x4 (&bpre)[WNT], bool has_bias) {
+                                                    int fq, int bz, const bf16x8 (&r2)[WNT / 2 > 0 ? WNT / 2 : 1][WMT],
+                                                    const bf16x4 (&r1)[WMT], bool has_res, const f32x4 (&bpre)[WNT], bool has_bias) {
   bf16* Y = reinterpret_cast<bf16*>(p.y) + (long)bz * p.y_bs;
   const int nb = n0 + wn * (16 * WNT);
 #pragma unroll
@@ -257,8 +257,8 @@ __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)
       if (has_res) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          a[e] += (float)rres[2 * u][j][e];
-          b[e] += (float)rres[2 * u + 1][j][e];
+          a[e] += (float)r2[u][j][e];
+          b[e] += (float)r2[u][j][4 + e];
         }
       }
       bf16x8 o;
@@ -275,7 +275,7 @@ __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)
         f32x4 a = finish(acc[WNT - 1][j], WNT - 1, n);
         if (has_res) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) a[e] += (float)rres[WNT - 1][j][e];
+          for (int e = 0; e < 4; ++e) a[e] += (float)r1[j][e];
         }
         bf16x4 o;
 #pragma unroll
@@ -532,8 +532,9 @@ __device__ __forceinline__ void wait_vmcnt() {  // s_waitcnt vmcnt(N) only (expc
   __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
 }
 
-template <int WNT, typename YT, bool CONV, int STAGES, int WMT, int KG, int NS = 1>
+template <int WNT, typename YT, bool CONV, int STAGES, int WMT, int KG, int NS = 1, bool PAIR = false>
 __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
+  static_assert(!PAIR || (sizeof(YT) == 2 && NS == 1), "paired columns: bf16 output, single-plane operands");
   // NS = 2: split-bf16 (fp32-class) operands - the activations arrive pre-split as two bf16 planes (hi = bf16(x),
   // lo = bf16(x - hi), written by the producing GroupNorm / split pass), the weights as their two packed planes; all four
   // are staged by LDS-DMA and every fragment pair costs three MFMAs (hi*hi + hi*lo + lo*hi).
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
 #pragma unroll
   for (int q = 0; q < WL; ++q) {
     const int pos = (wave + NW * q) * 8 + rsub;                     // LDS row of the weight tile this lane stages
-    const int n = n0 + (p.pair ? unpair_col<WNT>(pos) : pos);     // the output column (= weight row) that lives there
+    const int n = n0 + (PAIR ? unpair_col<WNT>(pos) : pos);       // the output column (= weight row) that lives there
     wok[q] = n < p.N && (wave + NW * q) < WRG;
     wrow_off[q] = (long)n * p.ldw;
   }
@@ -708,63 +709,50 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
   const int fq = lane >> 4;
   // residual tile of this lane, fetched first so that its latency hides under the whole K loop (bf16 outputs); being the
   // oldest loads in flight they are retired by the first counted wait
-  bf16x4 rres[WNT][WMT];
+  // The loads below are UNCONDITIONAL on clamped, always-valid addresses (rows >= M / columns >= N are never used by the
+  // epilogue): a `cond ? load : 0` select made the compiler zero-fill, branch and - worse - wait (s_waitcnt vmcnt(0)) right
+  // behind every load, which serialised the residual latency in front of the first DMA of every block.
+  // PAIR: one 16-byte load per tile pair (r2) plus an 8-byte one for an odd last tile (r1).
+  bf16x4 rres[PAIR ? 1 : WNT][PAIR ? 1 : WMT];
+  bf16x8 r2[PAIR ? (WNT / 2 > 0 ? WNT / 2 : 1) : 1][PAIR ? WMT : 1];
+  bf16x4 r1[PAIR ? WMT : 1];
   f32x4 bpre[WNT];
-  bool pair_res = false, pair_bias = false;
-  const bool pre_res = sizeof(YT) == 2 && p.res && p.splits == 1 && (p.ldr & 3) == 0 && p.epi != CRG_EPI_GEGLU;
-  const bool pre_bias = p.bias_mode == CRG_BIAS_COL && p.splits == 1 && p.epi != CRG_EPI_GEGLU;
-  if (p.pair) {
-    // paired mapping (host guarantees bf16 output, N % 8 == 0, 16-byte aligned rows of y / residual, no split-K, no GEGLU)
-    pair_res = p.res != nullptr;
-    pair_bias = p.bias_mode == CRG_BIAS_COL;
-    if (kg == 0) {
-      const int nb = n0 + wn * (16 * WNT);
-      if (pair_res) {
-        const bf16* R = reinterpret_cast<const bf16*>(p.res) + (long)bz * p.r_bs;
-#pragma unroll
-        for (int j = 0; j < WMT; ++j) {
-          const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
-#pragma unroll
-          for (int u = 0; u < WNT / 2; ++u) {
-            const int n = nb + 32 * u + 8 * fq;
-            const bf16x8 r8 = (m < p.M && n < p.N) ? *reinterpret_cast<const bf16x8*>(R + (long)m * p.ldr + n) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            rres[2 * u][j] = bf16x4{r8[0], r8[1], r8[2], r8[3]};
-            rres[2 * u + 1][j] = bf16x4{r8[4], r8[5], r8[6], r8[7]};
-          }
-          if constexpr (WNT & 1) {
-            const int n = nb + 16 * (WNT - 1) + 4 * fq;
-            rres[WNT - 1][j] = (m < p.M && n < p.N) ? *reinterpret_cast<const bf16x4*>(R + (long)m * p.ldr + n) : bf16x4{0, 0, 0, 0};
-          }
-        }
-      }
-      if (pair_bias) {
-#pragma unroll
-        for (int i = 0; i < WNT; ++i) {
-          const int n = (i < 2 * (WNT / 2)) ? nb + 32 * (i >> 1) + 8 * fq + 4 * (i & 1) : nb + 16 * i + 4 * fq;
-          bpre[i] = n < p.N ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-    }
-  } else {
-    if (pre_res && kg == 0) {
+  const bool pre_res = sizeof(YT) == 2 && p.res && p.splits == 1 && (p.ldr & 3) == 0 && (p.N & 3) == 0 && p.epi != CRG_EPI_GEGLU;
+  const bool pre_bias = p.bias_mode == CRG_BIAS_COL && p.splits == 1 && (p.N & 3) == 0 && p.epi != CRG_EPI_GEGLU;
+  if (kg == 0) {
+    const int nb = n0 + wn * (16 * WNT);
+    if (pre_res) {
       const bf16* R = reinterpret_cast<const bf16*>(p.res) + (long)bz * p.r_bs;
 #pragma unroll
       for (int j = 0; j < WMT; ++j) {
         const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
+        const bf16* Rm = R + (long)(m < p.M ? m : p.M - 1) * p.ldr;
+        if constexpr (PAIR) {
 #pragma unroll
-        for (int i = 0; i < WNT; ++i) {
-          const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
-          rres[i][j] = (m < p.M && n + 4 <= p.N) ? *reinterpret_cast<const bf16x4*>(R + (long)m * p.ldr + n) : bf16x4{0, 0, 0, 0};
+          for (int u = 0; u < WNT / 2; ++u) {
+            const int n = nb + 32 * u + 8 * fq;
+            r2[u][j] = *reinterpret_cast<const bf16x8*>(Rm + (n + 8 <= p.N ? n : p.N - 8));
+          }
+          if constexpr (WNT & 1) {
+            const int n = nb + 16 * (WNT - 1) + 4 * fq;
+            r1[j] = *reinterpret_cast<const bf16x4*>(Rm + (n + 4 <= p.N ? n : p.N - 4));
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < WNT; ++i) {
+            const int n = nb + i * 16 + fq * 4;
+            rres[i][j] = *reinterpret_cast<const bf16x4*>(Rm + (n + 4 <= p.N ? n : p.N - 4));
+          }
         }
       }
     }
     // column bias of this lane's 4-wide output groups: also fetched ahead of the K loop (a lone block per CU would otherwise
     // pay a full global-load latency between its last MFMA and its first store)
-    if (pre_bias && kg == 0) {
+    if (pre_bias) {
 #pragma unroll
       for (int i = 0; i < WNT; ++i) {
-        const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
-        bpre[i] = n + 4 <= p.N ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int n = (PAIR && i < 2 * (WNT / 2)) ? nb + 32 * (i >> 1) + 8 * fq + 4 * (i & 1) : nb + 16 * i + 4 * fq;
+        bpre[i] = *reinterpret_cast<const f32x4*>(p.bias + (n + 4 <= p.N ? n : p.N - 4));
       }
     }
   }
@@ -835,13 +823,11 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
 #pragma unroll
       for (int j = 0; j < WMT; ++j) acc[i][j] += red[(i * WMT + j) * 64];
   }
-  if constexpr (sizeof(YT) == 2 && NS == 1) {
-    if (p.pair) {
-      gemm_epilogue_pairs<WNT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, bz, rres, pair_res, bpre, pair_bias);
-      return;
-    }
+  if constexpr (PAIR) {
+    gemm_epilogue_pairs<WNT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, bz, r2, r1, pre_res, bpre, pre_bias);
+  } else {
+    gemm_epilogue<WNT, YT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid, rres, pre_res, bpre, pre_bias);
   }
-  gemm_epilogue<WNT, YT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid, rres, pre_res, bpre, pre_bias);
 }
 
 // Split-K second pass: y = epi(sum_s slab[s] + bias) + cvec + residual, 4 consecutive n per thread.
@@ -950,25 +936,25 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   constexpr int BN = 32 * WNT;
   constexpr bool GLDS = (NSPLIT == 1) && (sizeof(AT) == 2);
   constexpr size_t lds = GLDS ? (size_t)STAGES * (32 * WMT + BN) * 128 + 1024 /* dummy-load target */ : (size_t)2 * NSPLIT * (BM + BN) * 128;
-  void (*kern)(GemmP);
-  if constexpr (GLDS) kern = gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG>;
-  else kern = gemm_kernel<WNT, NSPLIT, AT, YT, CONV, NSPLIT>;  // split-bf16: 8 waves (two k-groups)
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", lds, hipGetErrorString(e));
-    attr_set = true;
-  }
   {
     const int nk_total = (p.K + BK - 1) / BK;
     p.ks_q = nk_total / p.splits;
     p.ks_r = nk_total % p.splits;
   }
-  static const bool pair_on = !(getenv("CRG_PAIR") && atoi(getenv("CRG_PAIR")) == 0);  // dev knob for A/B runs
-  p.pair = (pair_on && GLDS && sizeof(YT) == 2 && p.splits == 1 && p.epi != CRG_EPI_GEGLU && (p.N & 7) == 0 && (p.ldy & 7) == 0 &&
+  p.pair = (GLDS && sizeof(YT) == 2 && p.splits == 1 && p.epi != CRG_EPI_GEGLU && (p.N & 7) == 0 && (p.ldy & 7) == 0 &&
             (p.y_bs & 7) == 0 && ((uintptr_t)p.y & 15) == 0 &&
             (!p.res || ((p.ldr & 7) == 0 && (p.r_bs & 7) == 0 && ((uintptr_t)p.res & 15) == 0)) &&
             (!p.cvec || (p.cvec_ld & 3) == 0)) ? 1 : 0;
+  void (*kern)(GemmP);
+  if constexpr (GLDS && sizeof(YT) == 2) kern = p.pair ? gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG, 1, true> : gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG>;
+  else if constexpr (GLDS) kern = gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG>;
+  else kern = gemm_kernel<WNT, NSPLIT, AT, YT, CONV, NSPLIT>;  // split-bf16: 8 waves (two k-groups)
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[p.pair]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", lds, hipGetErrorString(e));
+    attr_set[p.pair] = true;
+  }
   dim3 grid(p.tile_count * p.splits, batch, 1);
   constexpr int slot = !GLDS ? (CONV ? CRG_K_CONV_X3 : CRG_K_GEMM_X3)
                              : (CONV ? (WNT == 5 ? CRG_K_CONV_W5 : WNT == 4 ? CRG_K_CONV_W4 : CRG_K_CONV_W1)

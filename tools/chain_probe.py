@@ -23,5 +23,5 @@ for (m, n, k) in [(2048, 1280, 1280), (8192, 640, 640), (32768, 320, 320), (2048
     ts = torch.tensor(list(buf), dtype=torch.float64).reshape(nb, 8)[:, :8]
     t0 = ts[:, 0].min()
     d = (ts - ts[:, :1]) / 100.0   # wall_clock64 ticks at 100 MHz -> us
-    print(f"{(m, n, k)}: per-block median us since entry: " + "  ".join(f"s{i}={d[:, i].median().item():.2f}" for i in (7, 1, 2, 3, 4, 6, 5)) +
+    print(f"{(m, n, k)}: per-block median us since entry: " + "  ".join(f"s{i}={d[:, i].median().item():.2f}" for i in (7, 2, 1, 6, 3, 4, 5)) +
           f" | block entry spread {((ts[:, 0].max() - t0) / 100.0).item():.2f} us, last stamp {((ts[:, 5].max() - t0) / 100.0).item():.2f} us")
