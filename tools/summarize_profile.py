@@ -32,13 +32,19 @@ def slot_of(name):
     """rocprofv3 kernel name (mangled, or mis-demangled: its demangler prints `__bf16, true` as `bool _Accum, bool, E`)
     -> cremage_amd._lib.SLOT_NAMES entry (enum crg_kernel_slot), or None for kernels that are not ours."""
     import re
-    m = re.search(r"gemm_glds_kernel(?:<|ILi)(\d)", name)
+    # gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG, NS, PAIR>: parse the arguments by position (PAIR is a bool too)
+    m = re.search(r"gemm_glds_kernelILi(\d)E(?:DF16b|DF16_|f)Lb([01])ELi\d+ELi\d+ELi\d+ELi(\d+)ELb[01]E", name)
     if m:
-        conv = ("Lb1E" in name) or ("bool _Accum" in name) or bool(re.search(r", true[,>]", name))
-        # NS = 2 (last template argument): the split-plane fp32-class variant is accounted in the x3 slots
-        if re.search(r"Lb[01]E(?:Li\d+E){3}Li2E", name) or re.search(r"(?:true|false|E), \d+, \d+, \d+, 2>", name):
+        wnt, conv, ns = m.group(1), m.group(2) == "1", m.group(3)
+    else:
+        m = re.search(r"gemm_glds_kernel<(\d), (bool _Accum, bool, E|[\w ]+, (?:true|false)), \d+, \d+, \d+, (\d+), (?:true|false)>", name)
+        if m:
+            wnt, ns = m.group(1), m.group(3)
+            conv = m.group(2).startswith("bool _Accum") or m.group(2).endswith("true")
+    if m:
+        if ns == "2":  # the split-plane fp32-class variant is accounted in the x3 slots
             return "conv_x3" if conv else "gemm_x3"
-        return ("conv_w" if conv else "gemm_w") + m.group(1)
+        return ("conv_w" if conv else "gemm_w") + wnt
     if "gemm_kernel" in name:
         return "conv_x3" if (("Lb1E" in name) or re.search(r", true[,>]", name)) else "gemm_x3"
     for pat, slot in (("splitk_reduce", "splitk_reduce"), ("attn_kernel", "attention"), ("gn_stats", "gn_stats"), ("gn_apply", "gn_apply"), ("gn_small", "gn_apply"),
