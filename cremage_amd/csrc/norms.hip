@@ -2,6 +2,7 @@
 // rows, row softmax.  All loads/stores are 16 bytes per lane (8 bf16 / 2x4 f32), rows are walked
 // with consecutive lanes on consecutive channels (fully coalesced NHWC rows).
 #include "crg_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -308,62 +309,125 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x, 
   }
 }
 
-// ---- LayerNorm: one wave per row, row kept in registers (dim <= 64 lanes * 8 * LN_MAXC) ----------
+// ---- LayerNorm: RW rows per wave and iteration, rows kept in registers (dim <= 64 lanes * 8 * NCH, NCH <= LN_MAXC) ----------
+// One row per wave and one wave-round per launch left a single 16-byte load per lane in flight and ran the launch as "everybody
+// loads, then everybody stores" (2.4 TB/s at dim 320).  Waves now walk the rows in a grid-stride loop, RW rows per step, and
+// request the next step's rows before reducing the current ones, so the read and the write streams overlap.
 constexpr int LN_MAXC = 4;  // dim <= 2048
-template <typename T>
+template <typename T, int NCH, int RW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ y, long rows, int dim,
                                                         float eps) {
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const long stride = (long)gridDim.x * 4 * RW;
+  long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (row0 >= rows) return;
   const int nch = dim >> 3;
-  const T* xr = x + row * dim;
-  crg_vec8<T> v[LN_MAXC];
-  float s = 0.f;
+  f32x4 g0[NCH], g1[NCH], b0[NCH], b1[NCH];
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nch) {
-      v[i].load(xr + ch * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[i].get(e);
-    }
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i < nch ? lane + 64 * i : 0;
+    g0[i] = *reinterpret_cast<const f32x4*>(gamma + ch * 8);
+    g1[i] = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
+    b0[i] = *reinterpret_cast<const f32x4*>(beta + ch * 8);
+    b1[i] = *reinterpret_cast<const f32x4*>(beta + ch * 8 + 4);
   }
+  crg_vec8<T> v[RW][NCH], nx[RW][NCH];
+  auto fetch = [&](crg_vec8<T> (&dst)[RW][NCH], long r0) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float mean = s / (float)dim;
-  float q = 0.f;
+    for (int r = 0; r < RW; ++r) {
+      const long row = r0 + r < rows ? r0 + r : rows - 1;  // clamped: a tail step re-reads the last row, stores are guarded
+      const T* xr = x + row * dim;
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nch) {
+      for (int i = 0; i < NCH; ++i)
+        if (lane + 64 * i < nch) dst[r][i].load(xr + (lane + 64 * i) * 8);
+    }
+  };
+  fetch(v, row0);
+  for (; row0 < rows; row0 += stride) {
+    const bool more = row0 + stride < rows;  // wave-uniform
+    if (more) fetch(nx, row0 + stride);
+    float s[RW], q[RW];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d = v[i].get(e) - mean;
-        q += d * d;
+    for (int r = 0; r < RW; ++r) {
+      s[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        if (lane + 64 * i < nch) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s[r] += v[r][i].get(e);
+        }
       }
     }
-  }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-  const float rstd = rsqrtf(q / (float)dim + eps);
-  T* yr = y + row * dim;
+    for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nch) {
-      crg_vec8<T> o;
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + ch * 8), b1 = *reinterpret_cast<const f32x4*>(beta + ch * 8 + 4);
+      for (int r = 0; r < RW; ++r) s[r] += __shfl_xor(s[r], o);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float ga = e < 4 ? g0[e] : g1[e - 4], be = e < 4 ? b0[e] : b1[e - 4];
-        o.set(e, (v[i].get(e) - mean) * rstd * ga + be);
+    for (int r = 0; r < RW; ++r) {
+      const float mean = s[r] / (float)dim;
+      s[r] = mean;
+      q[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        if (lane + 64 * i < nch) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = v[r][i].get(e) - mean;
+            q[r] += d * d;
+          }
+        }
       }
-      o.store(yr + ch * 8);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < RW; ++r) q[r] += __shfl_xor(q[r], o);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      if (row0 + r < rows) {
+        const float mean = s[r], rstd = rsqrtf(q[r] / (float)dim + eps);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int ch = lane + 64 * i;
+          if (ch < nch) {
+            crg_vec8<T> o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float ga = e < 4 ? g0[i][e] : g1[i][e - 4], be = e < 4 ? b0[i][e] : b1[i][e - 4];
+              o.set(e, (v[r][i].get(e) - mean) * rstd * ga + be);
+            }
+            o.store(y + (row0 + r) * dim + ch * 8);
+          }
+        }
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) v[r][i] = nx[r][i];
     }
   }
+}
+
+template <typename T>
+static void launch_layernorm(hipStream_t st, const T* x, const float* gamma, const float* beta, T* y, long rows, int dim, float eps) {
+  const int nchunks = (dim / 8 + 63) / 64;
+  // few rows: one row per wave so that the grid still covers the chip; many rows: at most 8 blocks per CU, the waves loop
+  const bool small = rows < 4 * 256 * 8;
+  static const int bpc = getenv("CRG_LN_BPC") ? atoi(getenv("CRG_LN_BPC")) : 8;  // dev knob: resident blocks per CU
+#define CRG_LN(NCH, RW)                                                                                                     \
+  do {                                                                                                                      \
+    long blocks = (rows + 4 * RW - 1) / (4 * RW);                                                                           \
+    if (blocks > 256 * bpc) blocks = 256 * bpc;                                                                                 \
+    hipLaunchKernelGGL((layernorm_kernel<T, NCH, RW>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta, y, rows, dim, eps); \
+  } while (0)
+  if (nchunks == 1) { if (small) CRG_LN(1, 1); else CRG_LN(1, 2); }
+  else if (nchunks == 2) { if (small) CRG_LN(2, 1); else CRG_LN(2, 2); }
+  else if (nchunks == 3) { if (small) CRG_LN(3, 1); else CRG_LN(3, 1); }
+  else CRG_LN(4, 1);
+#undef CRG_LN
 }
 
 // ---- row softmax: one block per row, y = softmax(x * scale) -----------------------------------------
@@ -489,11 +553,10 @@ extern "C" int crg_layernorm(crg_ctx* ctx, void* stream, const void* x, const fl
   hipStream_t st = (hipStream_t)stream;
   const double elems = (double)rows * dim;
   crg_prof_scope ps(ctx, st, CRG_K_LAYERNORM, 8.0 * elems, elems * crg_dtype_size(dtype) * 2);
-  dim3 grid((unsigned)((rows + 3) / 4));
   if (dtype == CRG_BF16)
-    hipLaunchKernelGGL(layernorm_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, gamma, beta, (bf16*)y, (long)rows, dim, eps);
+    launch_layernorm<bf16>(st, (const bf16*)x, gamma, beta, (bf16*)y, (long)rows, dim, eps);
   else if (dtype == CRG_F32)
-    hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y, (long)rows, dim, eps);
+    launch_layernorm<float>(st, (const float*)x, gamma, beta, (float*)y, (long)rows, dim, eps);
   else
     return crg_fail(ctx, -22, "layernorm: dtype %d unsupported", dtype);
   CRG_CHECK_LAUNCH(ctx, "layernorm");
