@@ -772,7 +772,12 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    // the DMA issue (address VALU + 1 KiB pieces) runs at raised wave priority: next to a wave of the CU's other block that
+    // streams MFMAs it was issued late and its data landed late (conv -2..3 % per shape, GEMM neutral; raising the priority
+    // of the MFMA phase instead was 4 % slower)
+    __builtin_amdgcn_s_setprio(2);
     if (kt + D < nk) stage(nbuf);
+    __builtin_amdgcn_s_setprio(0);
     const char* xs = smem + buf * STAGE_BYTES;
     const char* ws = xs + NS * XS_BYTES;
 #pragma unroll
