@@ -28,6 +28,20 @@ struct AttnP {
   float scale_log2;
 };
 
+#ifdef CRG_ATTN_LAPS
+// dev instrumentation (tools/attn_phase_probe.py, build with tools/build_variant.sh laps -DCRG_ATTN_LAPS): wall_clock64 laps of
+// wave 0 of the first 32 query blocks of head 0
+__device__ unsigned long long crg_attn_laps[32 * 8];
+#define LAP(i)                                       \
+  do {                                               \
+    const unsigned long long now_ = wall_clock64(); \
+    lap[i] += now_ - tl;                             \
+    tl = now_;                                       \
+  } while (0)
+#else
+#define LAP(i)
+#endif
+
 constexpr int VROW = 136;  // bytes per V^T LDS row (64 keys * 2 B + 8 pad)
 
 template <int KS, int NV, bool ONES>
@@ -43,8 +57,21 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (private 4 MB L2 each).  In launch order the query
+  // blocks of one (batch, head) land on all 8 XCDs and every L2 streams every head's K / V^T; the remap hands each XCD a
+  // contiguous run of (head, query block) pairs, so a head's K / V^T is fetched by one XCD only (-1.5 % at 4096 tokens).
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int nqb = gridDim.x, total = nqb * gridDim.y;
+    if ((total & 7) == 0) {
+      const int id = bx + nqb * by;
+      const int L = (id & 7) * (total >> 3) + (id >> 3);
+      by = L / nqb;
+      bx = L - by * nqb;
+    }
+  }
+  const int b = by / p.H, h = by % p.H;
+  const int q0 = bx * 128 + wave * 32;
 
   const bf16* Q = p.q + (long)b * p.Nq * p.ldq + (long)h * p.Dh;
   const bf16* K = p.k + (long)b * p.Nk * p.ldk + (long)h * p.Dh;
@@ -151,12 +178,17 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
   };
 
   const int ntiles = (p.Nk + 63) / 64;
+#ifdef CRG_ATTN_LAPS
+  unsigned long long lap[5] = {0, 0, 0, 0, 0}, tl = wall_clock64();
+#endif
   prefetch(0);
   commit(0);
   __syncthreads();
   for (int tile = 0; tile < ntiles; ++tile) {
     const bool more = tile + 1 < ntiles;
+    LAP(4);
     if (more) prefetch(tile + 1);
+    LAP(0);
     const char* Ks = smem + (tile & 1) * (KBYTES + VBYTES);
     const char* Vs = Ks + KBYTES;
 
@@ -172,6 +204,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
         st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kb], 0, 0, 0);
       }
     }
+    LAP(1);
     // ---- online softmax in base 2: p = exp2(s * scale_log2 - m); the max is taken on the raw scores ----
     const bool last = (tile + 1 == ntiles) && (p.Nk & 63);
     if (last) {
@@ -219,6 +252,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[kb][s2][j] = (bf16)st[kb][8 * s2 + j];
+    LAP(2);
     // ---- O^T += V^T P^T ----
 #pragma unroll
     for (int dv = 0; dv < NV; ++dv) {
@@ -234,9 +268,16 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
           oacc[dv] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], oacc[dv], 0, 0, 0);
         }
     }
+    LAP(3);
     if (more) commit((tile + 1) & 1);
     __syncthreads();
   }
+#ifdef CRG_ATTN_LAPS
+  if (by == 0 && bx < 32 && t == 0) {
+    LAP(4);
+    for (int i = 0; i < 5; ++i) crg_attn_laps[bx * 8 + i] = lap[i];
+  }
+#endif
 
   // ---- normalise and store: lane = query, registers = channels (4 consecutive per group) ----
   float l_tot;
@@ -314,3 +355,9 @@ extern "C" int crg_attention(crg_ctx* ctx, void* stream, const void* q, int64_t 
   }
   return crg_fail(ctx, -22, "attention: head dim %d unsupported", Dh);
 }
+
+#ifdef CRG_ATTN_LAPS
+extern "C" int crg_debug_read_attn(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(crg_attn_laps), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
