@@ -250,10 +250,11 @@ def test_group_norm_concat(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("dim", [64, 320, 640, 1280])
-def test_layer_norm(dtype, dim):
+@pytest.mark.parametrize("rows", [37, 8191, 20001])  # one row per wave / grid-stride steps of RW rows with an odd tail / > one sweep
+@pytest.mark.parametrize("dim", [64, 320, 640, 1280, 2048])
+def test_layer_norm(dtype, dim, rows):
     from cremage_amd import ops
-    x = rnd(2, 37, dim, seed=60) + 0.5
+    x = rnd(2, rows, dim, seed=60) + 0.5
     g, b = 1 + 0.1 * rnd(dim, seed=61), 0.1 * rnd(dim, seed=62)
     ref = F.layer_norm(q(x, dtype), (dim,), g, b, 1e-5)
     got = ops.layer_norm(x.to(_dev()).to(dtype), g.to(_dev()), b.to(_dev()), 1e-5)
