@@ -173,27 +173,38 @@ def test_conv2d_tile_configs(N, C, Co, hw):
     check(got, ref, BF, f"conv cfg {N}x{C}x{hw}x{hw}->{Co}")
 
 
-def test_split_planes_path():
+@pytest.mark.parametrize("C,Co,ks", [(64, 96, 3), (32, 64, 3), (128, 160, 3), (128, 3, 3), (64, 128, 1), (40, 64, 1)])
+def test_split_planes_path(C, Co, ks):
     """fp32-class operands as pre-split bf16 planes (crg_split_bf16 / crg_groupnorm_split -> crg_conv_args.x_lo): the planes
-    reproduce the fp32 tensor to 2^-16, and the 4-plane LDS-DMA conv equals the register-staged fp32-class conv."""
+    reproduce the fp32 tensor to 2^-16, and the 4-plane LDS-DMA conv equals the register-staged fp32-class conv and an fp64
+    reference (chunk-major and tap-major weight layouts, 1x1 and 3x3, thin outputs)."""
     from cremage_amd import ops
-    x = rnd(2, 64, 24, 20, seed=70, scale=3.0) + 1.0
+    x = rnd(2, C, 24, 20, seed=70, scale=3.0) + 1.0
     xd = nhwc(x, torch.float32)
     hi, lo = ops.split_bf16(xd)
     assert hi.dtype == lo.dtype == BF and hi.shape == xd.shape
     rec = hi.float() + lo.float()
     assert ((rec - xd).abs() / xd.abs().clamp_min(1e-3)).max().item() < 2.0 ** -15
-    g, b = 1 + 0.1 * rnd(64, seed=71), 0.1 * rnd(64, seed=72)
-    ref = ops.group_norm(xd, g.to(_dev()), b.to(_dev()), 32, 1e-6, silu=True)
-    gh, gl = ops.group_norm(xd, g.to(_dev()), b.to(_dev()), 32, 1e-6, silu=True, split=True)
+    groups = 32 if C % 32 == 0 else 8
+    g, b = 1 + 0.1 * rnd(C, seed=71), 0.1 * rnd(C, seed=72)
+    ref = ops.group_norm(xd, g.to(_dev()), b.to(_dev()), groups, 1e-6, silu=True)
+    gh, gl = ops.group_norm(xd, g.to(_dev()), b.to(_dev()), groups, 1e-6, silu=True, split=True)
     assert (gh.float() + gl.float() - ref).abs().max().item() < 1e-4
-    w, bias = rnd(96, 64, 3, 3, seed=73, scale=(64 * 9) ** -0.5), rnd(96, seed=74)
-    res = nhwc(rnd(2, 96, 24, 20, seed=75), torch.float32)
-    for kw in (dict(), dict(residual=res), dict(stride=2, padding=(0, 0, 1, 1)), dict(upsample2x=True)):
+    w, bias = rnd(Co, C, ks, ks, seed=73, scale=(C * ks * ks) ** -0.5), rnd(Co, seed=74)
+    res = nhwc(rnd(2, Co, 24, 20, seed=75), torch.float32)
+    variants = (dict(), dict(residual=res), dict(stride=2, padding=(0, 0, 1, 1)), dict(upsample2x=True)) if ks == 3 else \
+        (dict(padding=0), dict(padding=0, residual=res))
+    for kw in variants:
         a = ops.conv2d(xd, w.to(_dev()), bias.to(_dev()), **kw)
         bb = ops.conv2d(hi, w.to(_dev()), bias.to(_dev()), x_lo=lo, **kw)
         assert bb.dtype == torch.float32 and bb.shape == a.shape
         assert (a - bb).abs().max().item() < 2e-5 * max(1.0, a.abs().max().item()), kw
+        ref64 = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest") if kw.get("upsample2x") else
+                         (F.pad(x.double(), (0, 1, 0, 1)) if kw.get("stride") == 2 else x.double()), w.double(), bias.double(),
+                         stride=kw.get("stride", 1), padding=0 if (ks == 1 or kw.get("stride") == 2) else 1)
+        if "residual" in kw:
+            ref64 = ref64 + res.double().cpu()
+        assert (bb.double().cpu() - ref64).abs().max().item() < 3e-5 * max(1.0, ref64.abs().max().item()), ("vs fp64", kw)
     with pytest.raises(Exception):
         ops.conv2d(hi, w.to(_dev()), bias.to(_dev()), x_lo=lo.float())
 
