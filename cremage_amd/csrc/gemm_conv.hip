@@ -18,6 +18,7 @@
 // for the UNet skip concat.  BF16X3 (NSPLIT=2) stages hi and lo bf16 planes of both operands and
 // issues hi*hi + hi*lo + lo*hi.
 #include "crg_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -41,6 +42,7 @@ struct GemmP {
   // of the n-fastest tile order; the split-K slab then only holds rows >= slab_row0
   int tile_base, tile_count, slab_row0;
   int pair;        // paired-column output mapping (see unpair_col): 16-byte epilogue accesses
+  int rowhalo;     // conv: eligible for conv3_rowhalo_kernel (3x3, stride 1, pad 1, chunk-major K, image width divides 128)
   int ks_q, ks_r;  // k-tiles per K-slice: nk_total = splits * ks_q + ks_r
   int xg_m, xg_n, xg_s;  // XCD partition of the (m-tile, n-tile, k-slice) grid, product 8; xg_s == 0: legacy contiguous order
 };
@@ -835,6 +837,218 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convs whose image width divides 128 (16, 32, 64, 128: every UNet level above 8x8), chunk-major K.
+// The plain implicit GEMM stages the activation tile once per TAP (9 x 16 KB per 64-channel chunk) although the three taps
+// of one kernel row read the same image rows shifted by one pixel.  Here a 128-pixel tile = R = 128 / W whole image rows;
+// per (chunk, kernel row kh) ONE buffer of R x (W + 2) pixels (the rows with a one-pixel halo left and right, zero outside
+// the image) is staged and the three taps kw = 0..2 read their A fragments from it at a pixel offset of kw.  Activation
+// bytes staged per chunk 144 -> 51 KB, all staged bytes per k-tile 36 -> 26 KB: the K loop of these kernels is bound by the
+// LDS-DMA fill (in-kernel laps: DMA issue 46 % of the conv K loop), not by MFMA issue.
+// LDS: weight ring 2 x BN x 128 B as before + 2 row buffers of <= 20 KB = 74-78 KB, still two blocks per CU.  The row buffer of
+// group g + 1 is filled during the three k-tiles of group g (its pieces are spread over them); every k-tile starts with
+// s_waitcnt vmcnt(0) + s_barrier, so each piece has landed and is visible before its first reader and the buffer it
+// overwrites (group g - 1's) has no reader left.
+template <int WNT, typename YT, bool PAIR>
+__global__ __launch_bounds__(256, 2) void conv3_rowhalo_kernel(GemmP p) {
+  static_assert(!PAIR || sizeof(YT) == 2, "paired columns: bf16 output");
+  constexpr int WMT = 4, NW = 4;
+  constexpr int BN = 32 * WNT;
+  constexpr int WS_BYTES = BN * 128;
+  constexpr int WRG = BN / 8;
+  constexpr int WL = (WRG + NW - 1) / NW;
+  constexpr int XI = 5;  // row-buffer pieces (8 pixels = 1 KiB) per wave and group: 128 + 2 R <= 160 pixels = 20 pieces
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int Wd = p.W, WP = Wd + 2;
+  const int R = 128 / Wd;
+  const int xpix = R * WP;
+  const int XP = (xpix + 7) >> 3;
+  const int xbuf_bytes = XP * 1024;
+  char* const wring = smem;
+  char* const xbuf = smem + 2 * WS_BYTES;
+
+  int tile_m, tile_n, sid;
+  block_to_tile(p, tile_m, tile_n, sid);
+  const int m0 = tile_m * 128, n0 = tile_n * BN;
+  const int bz = 0;
+  const bf16* Wp = p.w;
+  const bf16* zpage = p.zero_page;
+  const int rsub = lane >> 3;
+  const int clog = (lane & 7) ^ rsub;
+
+  // row-buffer pieces of this lane: piece jp = wave + 4 i covers buffer pixels 8 jp .. 8 jp + 7, this lane pixel 8 jp + rsub
+  int xsrc[XI];        // source pixel index (kernel row kh = 1), valid when a mask bit is set
+  unsigned xmask[XI];  // bit kh: source row h + kh - 1 inside the image (and pixel inside the tile / image / problem)
+  {
+    const int rows_total = p.M / Wd;  // N * H image rows
+    const int row0 = m0 / Wd;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int b = 8 * (wave + 4 * i) + rsub;
+      const int r = b / WP, col = b - r * WP;
+      const int grow = row0 + r;
+      const int img = grow / p.H, h = grow - img * p.H;
+      const int w = col - 1;
+      const bool ok = b < xpix && grow < rows_total && w >= 0 && w < Wd;
+      unsigned msk = 0;
+      if (ok) msk = (h >= 1 ? 1u : 0u) | 2u | (h + 1 < p.H ? 4u : 0u);
+      xmask[i] = msk;
+      xsrc[i] = grow * Wd + w;
+    }
+  }
+  bool wok[WL];
+  long wrow_off[WL];
+#pragma unroll
+  for (int q = 0; q < WL; ++q) {
+    const int pos = (wave + NW * q) * 8 + rsub;
+    const int n = n0 + (PAIR ? unpair_col<WNT>(pos) : pos);
+    wok[q] = n < p.N && (wave + NW * q) < WRG;
+    wrow_off[q] = (long)n * p.ldw;
+  }
+  // K slice of this block in (chunk, kernel row) groups of three k-tiles (ks_q / ks_r are in groups for this kernel)
+  const int g_begin = sid * p.ks_q + (sid < p.ks_r ? sid : p.ks_r);
+  const int g_end = g_begin + p.ks_q + (sid < p.ks_r ? 1 : 0);
+
+  auto stage_x = [&](int g, int slot) {  // this wave's pieces i with i % 3 == slot of group g's row buffer
+    const int c = g / 3, kh = g - 3 * c;
+    const int cch = c * 64 + clog * 8;
+    const bool second = cch >= p.C1;
+    const bf16* base = reinterpret_cast<const bf16*>(second ? p.x2 : p.a);
+    const int Cs = second ? p.C2 : p.C1;
+    const int cs = second ? cch - p.C1 : cch;
+    char* xb = xbuf + ((g - g_begin) & 1) * xbuf_bytes;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      if (i % 3 != slot) continue;
+      const int jp = wave + 4 * i;
+      if (jp < XP) {  // wave-uniform
+        const bool ok = (xmask[i] >> kh) & 1u;
+        const bf16* src = ok ? base + (long)(xsrc[i] + (kh - 1) * Wd) * Cs + cs : zpage;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xb + jp * 1024), 16, 0, 0);
+      }
+    }
+  };
+  auto stage_w = [&](int kt, int buf) {  // weight k-tile kt (64 K-elements) of this block's BN rows
+    char* ws = wring + buf * WS_BYTES;
+    const long kc = (long)kt * BK + clog * 8;
+#pragma unroll
+    for (int q = 0; q < WL; ++q) {
+      if ((wave + NW * q) < WRG) {  // wave-uniform
+        const bf16* src = wok[q] ? Wp + wrow_off[q] + kc : zpage;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ws + (wave + NW * q) * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[WNT][WMT];
+#pragma unroll
+  for (int i = 0; i < WNT; ++i)
+#pragma unroll
+    for (int j = 0; j < WMT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fq = lane >> 4;
+  // buffer pixel of this lane's output pixels (tap kw adds kw): output pixel (r, w) of the tile sits at r * (W + 2) + w + 1 - 1 + kw
+  int xb0[WMT];
+#pragma unroll
+  for (int j = 0; j < WMT; ++j) {
+    const int ml = wm * 64 + j * 16 + frow;
+    const int r = ml / Wd;
+    xb0[j] = r * WP + (ml - r * Wd);
+  }
+
+  // residual / bias prefetch: as in gemm_glds_kernel (unconditional loads on clamped addresses)
+  bf16x4 rres[PAIR ? 1 : WNT][PAIR ? 1 : WMT];
+  bf16x8 r2[PAIR ? (WNT / 2 > 0 ? WNT / 2 : 1) : 1][PAIR ? WMT : 1];
+  bf16x4 r1[PAIR ? WMT : 1];
+  f32x4 bpre[WNT];
+  const bool pre_res = sizeof(YT) == 2 && p.res && p.splits == 1 && (p.ldr & 3) == 0 && (p.N & 3) == 0;
+  const bool pre_bias = p.bias_mode == CRG_BIAS_COL && p.splits == 1 && (p.N & 3) == 0;
+  {
+    const int nb = n0 + wn * (16 * WNT);
+    if (pre_res) {
+      const bf16* Rp = reinterpret_cast<const bf16*>(p.res);
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + frow;
+        const bf16* Rm = Rp + (long)(m < p.M ? m : p.M - 1) * p.ldr;
+        if constexpr (PAIR) {
+#pragma unroll
+          for (int u = 0; u < WNT / 2; ++u) {
+            const int n = nb + 32 * u + 8 * fq;
+            r2[u][j] = *reinterpret_cast<const bf16x8*>(Rm + (n + 8 <= p.N ? n : p.N - 8));
+          }
+          if constexpr (WNT & 1) {
+            const int n = nb + 16 * (WNT - 1) + 4 * fq;
+            r1[j] = *reinterpret_cast<const bf16x4*>(Rm + (n + 4 <= p.N ? n : p.N - 4));
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < WNT; ++i) {
+            const int n = nb + i * 16 + fq * 4;
+            rres[i][j] = *reinterpret_cast<const bf16x4*>(Rm + (n + 4 <= p.N ? n : p.N - 4));
+          }
+        }
+      }
+    }
+    if (pre_bias) {
+#pragma unroll
+      for (int i = 0; i < WNT; ++i) {
+        const int n = (PAIR && i < 2 * (WNT / 2)) ? nb + 32 * (i >> 1) + 8 * fq + 4 * (i & 1) : nb + 16 * i + 4 * fq;
+        bpre[i] = *reinterpret_cast<const f32x4*>(p.bias + (n + 4 <= p.N ? n : p.N - 4));
+      }
+    }
+  }
+
+  if (g_begin < g_end) {
+    stage_x(g_begin, 0);
+    stage_x(g_begin, 1);
+    stage_x(g_begin, 2);
+    stage_w(3 * g_begin, 0);
+  }
+  int wbuf = 0;
+  for (int g = g_begin; g < g_end; ++g) {
+    const char* xs = xbuf + ((g - g_begin) & 1) * xbuf_bytes;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      wait_vmcnt<0>();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_setprio(2);
+      if (kw < 2 || g + 1 < g_end) stage_w(3 * g + kw + 1, wbuf ^ 1);
+      if (g + 1 < g_end) stage_x(g + 1, kw);
+      __builtin_amdgcn_s_setprio(0);
+      const char* ws = wring + wbuf * WS_BYTES;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        bf16x8 xf[WMT], wf[WNT];
+#pragma unroll
+        for (int j = 0; j < WMT; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xs + lds_off(xb0[j] + kw, k2 * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < WNT; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(ws + lds_off(wn * (16 * WNT) + i * 16 + frow, k2 * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < WNT; ++i)
+#pragma unroll
+          for (int j = 0; j < WMT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      }
+      wbuf ^= 1;
+    }
+  }
+  if constexpr (PAIR) {
+    gemm_epilogue_pairs<WNT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, bz, r2, r1, pre_res, bpre, pre_bias);
+  } else {
+    gemm_epilogue<WNT, YT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid, rres, pre_res, bpre, pre_bias);
+  }
+}
+
 // Split-K second pass: y = epi(sum_s slab[s] + bias) + cvec + residual, 4 consecutive n per thread.
 template <typename YT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p) {
@@ -954,18 +1168,33 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   if constexpr (GLDS && sizeof(YT) == 2) kern = p.pair ? gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG, 1, true> : gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG>;
   else if constexpr (GLDS) kern = gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG>;
   else kern = gemm_kernel<WNT, NSPLIT, AT, YT, CONV, NSPLIT>;  // split-bf16: 8 waves (two k-groups)
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[p.pair]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", lds, hipGetErrorString(e));
-    attr_set[p.pair] = true;
+  size_t lds_bytes = lds;
+  bool halo = false;
+  if constexpr (GLDS && CONV && STAGES == 2 && WMT == 4 && KG == 1 && sizeof(YT) == 2 && (WNT == 4 || WNT == 5)) {
+    static const int knob = getenv("CRG_ROWHALO") ? atoi(getenv("CRG_ROWHALO")) : 1;  // dev knob: 0 = plain implicit GEMM
+    const int ngroups = (p.K / BK) / 3;
+    if (knob && p.rowhalo && batch == 1 && p.splits <= ngroups) {
+      halo = true;
+      kern = p.pair ? conv3_rowhalo_kernel<WNT, YT, true> : conv3_rowhalo_kernel<WNT, YT, false>;
+      const int R = 128 / p.W, XP = (R * (p.W + 2) + 7) / 8;
+      lds_bytes = (size_t)2 * BN * 128 + (size_t)2 * XP * 1024;
+      p.ks_q = ngroups / p.splits;  // K slices in (chunk, kernel row) groups
+      p.ks_r = ngroups % p.splits;
+    }
+  }
+  static bool attr_set[4] = {false, false, false, false};
+  if (!attr_set[p.pair + 2 * halo]) {
+    const size_t cap = halo ? (size_t)80 * 1024 : lds;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+    if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", cap, hipGetErrorString(e));
+    attr_set[p.pair + 2 * halo] = true;
   }
   dim3 grid(p.tile_count * p.splits, batch, 1);
   constexpr int slot = !GLDS ? (CONV ? CRG_K_CONV_X3 : CRG_K_GEMM_X3)
                              : (CONV ? (WNT == 5 ? CRG_K_CONV_W5 : WNT == 4 ? CRG_K_CONV_W4 : CRG_K_CONV_W1)
                                      : (WNT == 5 ? CRG_K_GEMM_W5 : WNT == 4 ? CRG_K_GEMM_W4 : CRG_K_GEMM_W1));
   crg_prof_scope ps(ctx, st, slot, wk.flops, wk.bytes);
-  hipLaunchKernelGGL(kern, grid, dim3(GLDS ? 256 * KG : 256 * NSPLIT), lds, st, p);
+  hipLaunchKernelGGL(kern, grid, dim3(GLDS ? 256 * KG : 256 * NSPLIT), lds_bytes, st, p);
   CRG_CHECK_LAUNCH(ctx, "gemm");
   return 0;
 }
@@ -1195,6 +1424,9 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
   p.H = a->H; p.W = a->W; p.Ho = a->Ho; p.Wo = a->Wo; p.ks = a->ksize; p.stride = a->stride;
   p.pad_t = a->pad_t; p.pad_l = a->pad_l; p.up = a->upsample2x;
   p.cm = (a->ksize == 3 && Ctot % 64 == 0) ? 1 : 0;  // must match crg_pack_weight's layout rule
+  p.rowhalo = (p.cm && a->stride == 1 && !a->upsample2x && a->pad_t == 1 && a->pad_l == 1 && a->Ho == a->H && a->Wo == a->W &&
+               a->W >= 16 && a->W <= 128 && 128 % a->W == 0 && a->C1 % 8 == 0 && a->x_dtype == CRG_BF16 && a->y_dtype == CRG_BF16 &&
+               a->prec == CRG_PREC_BF16) ? 1 : 0;
   const double flops = 2.0 * p.M * (double)p.N * p.K;
   const double bytes = (double)a->N * a->H * a->W * Ctot * crg_dtype_size(a->x_dtype) + (double)p.N * p.K * 2 +
                        (double)p.M * p.N * crg_dtype_size(a->y_dtype) * (a->residual ? 2 : 1);

@@ -209,6 +209,32 @@ def test_split_planes_path(C, Co, ks):
         ops.conv2d(hi, w.to(_dev()), bias.to(_dev()), x_lo=lo.float())
 
 
+@pytest.mark.parametrize("N,C1,C2,H,W,Co", [
+    (2, 64, 0, 16, 16, 64),       # one chunk, tiles of 8 image rows
+    (1, 128, 64, 24, 32, 160),    # virtual concat, H != W, 160-wide tiles
+    (3, 64, 0, 5, 16, 96),        # M = 240: tile tail, tiles straddling images
+    (2, 72, 56, 16, 32, 64),      # concat boundary inside a 64-channel chunk
+    (1, 1280, 0, 16, 16, 128),    # long K: split-K slices in (chunk, kernel row) groups
+    (1, 64, 0, 4, 128, 64),       # one image row per tile
+    (2, 320, 0, 64, 64, 320),     # production shape (SD1.5 64x64 level)
+    (8, 640, 0, 32, 32, 640),     # production shape: 256 tiles -> two K slices
+])
+def test_conv_rowhalo_shapes(N, C1, C2, H, W, Co):
+    """3x3 / stride 1 / pad 1 convs whose width divides 128 run on conv3_rowhalo_kernel (one halo'd row buffer per kernel row
+    instead of one activation tile per tap): image borders, tile tails, concat inputs, split-K and every fused epilogue term."""
+    from cremage_amd import ops
+    C = C1 + C2
+    x = rnd(N, C1, H, W, seed=80)
+    x2 = rnd(N, C2, H, W, seed=81) if C2 else None
+    w, b = rnd(Co, C, 3, 3, seed=82, scale=(9 * C) ** -0.5), rnd(Co, seed=83)
+    res, cvec = rnd(N, Co, H, W, seed=84), rnd(N, Co, seed=85)
+    for kw in (dict(), dict(res=res), dict(cvec=cvec, res=res)):
+        ref = conv_ref(x, w, b, BF, x2=x2, **kw)
+        got = ops.conv2d(nhwc(x, BF), w.to(_dev()), b.to(_dev()), x2=nhwc(x2, BF) if C2 else None,
+                         cvec=kw["cvec"].to(_dev()) if "cvec" in kw else None, residual=nhwc(kw["res"], BF) if "res" in kw else None)
+        check(got, ref, BF, f"rowhalo conv {N}x{C1}+{C2}x{H}x{W}->{Co} {sorted(kw)}")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_unet_shapes(dtype):
     """production channel counts at small spatial size (tile tails in both M and N)"""
