@@ -849,15 +849,20 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
 // group g + 1 is filled during the three k-tiles of group g (its pieces are spread over them); every k-tile starts with
 // s_waitcnt vmcnt(0) + s_barrier, so each piece has landed and is visible before its first reader and the buffer it
 // overwrites (group g - 1's) has no reader left.
-template <int WNT, typename YT, bool PAIR>
-__global__ __launch_bounds__(256, 2) void conv3_rowhalo_kernel(GemmP p) {
-  static_assert(!PAIR || sizeof(YT) == 2, "paired columns: bf16 output");
-  constexpr int WMT = 4, NW = 4;
+// NS = 2 (with KG = 2: eight waves, the second k-group multiplies the second 32-wide k-step, folded through LDS at the end): the
+// split-bf16 fp32-class form on pre-split planes (VAE) - activation hi / lo row buffers and weight hi / lo ring, three MFMAs per
+// fragment pair; 132 KB, one block per CU like the 4-plane kernel it replaces, but 43 instead of 64 KB staged per k-tile.
+// Widths that are multiples of 128 (VAE levels 128..512) use one row SEGMENT of 128 pixels per tile (R = 1, halo = the
+// neighbouring pixels of the same row).
+template <int WNT, typename YT, bool PAIR, int NS = 1, int KG = 1>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3_rowhalo_kernel(GemmP p) {
+  static_assert(!PAIR || (sizeof(YT) == 2 && NS == 1), "paired columns: bf16 output, single-plane operands");
+  constexpr int WMT = 4, NW = 4 * KG;
   constexpr int BN = 32 * WNT;
   constexpr int WS_BYTES = BN * 128;
   constexpr int WRG = BN / 8;
   constexpr int WL = (WRG + NW - 1) / NW;
-  constexpr int XI = 5;  // row-buffer pieces (8 pixels = 1 KiB) per wave and group: 128 + 2 R <= 160 pixels = 20 pieces
+  constexpr int XI = (20 + NW - 1) / NW;  // row-buffer pieces (8 pixels = 1 KiB) per wave, group and plane: 128 + 2 R <= 160 pixels = 20 pieces
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -865,37 +870,43 @@ __global__ __launch_bounds__(256, 2) void conv3_rowhalo_kernel(GemmP p) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int Wd = p.W, WP = Wd + 2;
-  const int R = 128 / Wd;
+  const int kg = wave >> 2;
+  const int wm = (wave & 3) >> 1, wn = wave & 1;
+  const int Wd = p.W;
+  const bool seg = Wd > 128;             // tile = 128-pixel segment of one image row
+  const int WP = seg ? 130 : Wd + 2;
+  const int R = seg ? 1 : 128 / Wd;
   const int xpix = R * WP;
   const int XP = (xpix + 7) >> 3;
-  const int xbuf_bytes = XP * 1024;
-  char* const wring = smem;
-  char* const xbuf = smem + 2 * WS_BYTES;
+  const int xbuf_bytes = XP * 1024;      // one plane of one row buffer
+  char* const wring = smem;              // [stage][plane][BN x 128 B]
+  char* const xbuf = smem + 2 * NS * WS_BYTES;  // [parity][plane][xbuf_bytes]
 
   int tile_m, tile_n, sid;
   block_to_tile(p, tile_m, tile_n, sid);
   const int m0 = tile_m * 128, n0 = tile_n * BN;
   const int bz = 0;
   const bf16* Wp = p.w;
+  const long a_lo_off = NS == 2 ? reinterpret_cast<const bf16*>(p.a_lo) - reinterpret_cast<const bf16*>(p.a) : 0;
+  const long w_lo_off = NS == 2 ? p.w_lo - p.w : 0;
   const bf16* zpage = p.zero_page;
   const int rsub = lane >> 3;
   const int clog = (lane & 7) ^ rsub;
 
-  // row-buffer pieces of this lane: piece jp = wave + 4 i covers buffer pixels 8 jp .. 8 jp + 7, this lane pixel 8 jp + rsub
+  // row-buffer pieces of this lane: piece jp = wave + NW i covers buffer pixels 8 jp .. 8 jp + 7, this lane pixel 8 jp + rsub
   int xsrc[XI];        // source pixel index (kernel row kh = 1), valid when a mask bit is set
   unsigned xmask[XI];  // bit kh: source row h + kh - 1 inside the image (and pixel inside the tile / image / problem)
   {
     const int rows_total = p.M / Wd;  // N * H image rows
     const int row0 = m0 / Wd;
+    const int w0 = m0 - row0 * Wd;    // first pixel of the segment (0 unless seg)
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      const int b = 8 * (wave + 4 * i) + rsub;
+      const int b = 8 * (wave + NW * i) + rsub;
       const int r = b / WP, col = b - r * WP;
       const int grow = row0 + r;
       const int img = grow / p.H, h = grow - img * p.H;
-      const int w = col - 1;
+      const int w = w0 + col - 1;
       const bool ok = b < xpix && grow < rows_total && w >= 0 && w < Wd;
       unsigned msk = 0;
       if (ok) msk = (h >= 1 ? 1u : 0u) | 2u | (h + 1 < p.H ? 4u : 0u);
@@ -916,33 +927,41 @@ __global__ __launch_bounds__(256, 2) void conv3_rowhalo_kernel(GemmP p) {
   const int g_begin = sid * p.ks_q + (sid < p.ks_r ? sid : p.ks_r);
   const int g_end = g_begin + p.ks_q + (sid < p.ks_r ? 1 : 0);
 
-  auto stage_x = [&](int g, int slot) {  // this wave's pieces i with i % 3 == slot of group g's row buffer
+  auto stage_x = [&](int g, int slot) {  // this wave's pieces i with i % 3 == slot of group g's row buffer(s)
     const int c = g / 3, kh = g - 3 * c;
     const int cch = c * 64 + clog * 8;
     const bool second = cch >= p.C1;
     const bf16* base = reinterpret_cast<const bf16*>(second ? p.x2 : p.a);
     const int Cs = second ? p.C2 : p.C1;
     const int cs = second ? cch - p.C1 : cch;
-    char* xb = xbuf + ((g - g_begin) & 1) * xbuf_bytes;
+    char* xb = xbuf + ((g - g_begin) & 1) * (NS * xbuf_bytes);
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       if (i % 3 != slot) continue;
-      const int jp = wave + 4 * i;
+      const int jp = wave + NW * i;
       if (jp < XP) {  // wave-uniform
         const bool ok = (xmask[i] >> kh) & 1u;
         const bf16* src = ok ? base + (long)(xsrc[i] + (kh - 1) * Wd) * Cs + cs : zpage;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xb + jp * 1024), 16, 0, 0);
+        if constexpr (NS == 2) {
+          const bf16* src2 = ok ? src + a_lo_off : zpage;
+          __builtin_amdgcn_global_load_lds((gptr_t)src2, (lptr_t)(xb + xbuf_bytes + jp * 1024), 16, 0, 0);
+        }
       }
     }
   };
   auto stage_w = [&](int kt, int buf) {  // weight k-tile kt (64 K-elements) of this block's BN rows
-    char* ws = wring + buf * WS_BYTES;
+    char* ws = wring + buf * (NS * WS_BYTES);
     const long kc = (long)kt * BK + clog * 8;
 #pragma unroll
     for (int q = 0; q < WL; ++q) {
       if ((wave + NW * q) < WRG) {  // wave-uniform
         const bf16* src = wok[q] ? Wp + wrow_off[q] + kc : zpage;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ws + (wave + NW * q) * 1024), 16, 0, 0);
+        if constexpr (NS == 2) {
+          const bf16* src2 = wok[q] ? src + w_lo_off : zpage;
+          __builtin_amdgcn_global_load_lds((gptr_t)src2, (lptr_t)(ws + WS_BYTES + (wave + NW * q) * 1024), 16, 0, 0);
+        }
       }
     }
   };
@@ -955,12 +974,12 @@ __global__ __launch_bounds__(256, 2) void conv3_rowhalo_kernel(GemmP p) {
 
   const int frow = lane & 15;
   const int fq = lane >> 4;
-  // buffer pixel of this lane's output pixels (tap kw adds kw): output pixel (r, w) of the tile sits at r * (W + 2) + w + 1 - 1 + kw
+  // buffer pixel of this lane's output pixels for tap kw = 0 (tap kw adds kw): output pixel (r, w) of the tile sits at r * WP + w
   int xb0[WMT];
 #pragma unroll
   for (int j = 0; j < WMT; ++j) {
     const int ml = wm * 64 + j * 16 + frow;
-    const int r = ml / Wd;
+    const int r = seg ? 0 : ml / Wd;
     xb0[j] = r * WP + (ml - r * Wd);
   }
 
@@ -971,7 +990,7 @@ __global__ __launch_bounds__(256, 2) void conv3_rowhalo_kernel(GemmP p) {
   f32x4 bpre[WNT];
   const bool pre_res = sizeof(YT) == 2 && p.res && p.splits == 1 && (p.ldr & 3) == 0 && (p.N & 3) == 0;
   const bool pre_bias = p.bias_mode == CRG_BIAS_COL && p.splits == 1 && (p.N & 3) == 0;
-  {
+  if (kg == 0) {
     const int nb = n0 + wn * (16 * WNT);
     if (pre_res) {
       const bf16* Rp = reinterpret_cast<const bf16*>(p.res);
@@ -1015,7 +1034,7 @@ __global__ __launch_bounds__(256, 2) void conv3_rowhalo_kernel(GemmP p) {
   }
   int wbuf = 0;
   for (int g = g_begin; g < g_end; ++g) {
-    const char* xs = xbuf + ((g - g_begin) & 1) * xbuf_bytes;
+    const char* xs = xbuf + ((g - g_begin) & 1) * (NS * xbuf_bytes);
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
       wait_vmcnt<0>();
@@ -1026,21 +1045,54 @@ __global__ __launch_bounds__(256, 2) void conv3_rowhalo_kernel(GemmP p) {
       if (kw < 2 || g + 1 < g_end) stage_w(3 * g + kw + 1, wbuf ^ 1);
       if (g + 1 < g_end) stage_x(g + 1, kw);
       __builtin_amdgcn_s_setprio(0);
-      const char* ws = wring + wbuf * WS_BYTES;
+      const char* ws = wring + wbuf * (NS * WS_BYTES);
 #pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        bf16x8 xf[WMT], wf[WNT];
+      for (int k2 = 0; k2 < 2 / KG; ++k2) {
+        const int ks = KG == 2 ? kg : k2;
+        bf16x8 xf[WMT], wf[WNT], xl[NS == 2 ? WMT : 1], wl[NS == 2 ? WNT : 1];
 #pragma unroll
-        for (int j = 0; j < WMT; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xs + lds_off(xb0[j] + kw, k2 * 4 + fq));
+        for (int j = 0; j < WMT; ++j) {
+          const int off = lds_off(xb0[j] + kw, ks * 4 + fq);
+          xf[j] = *reinterpret_cast<const bf16x8*>(xs + off);
+          if constexpr (NS == 2) xl[j] = *reinterpret_cast<const bf16x8*>(xs + xbuf_bytes + off);
+        }
 #pragma unroll
-        for (int i = 0; i < WNT; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(ws + lds_off(wn * (16 * WNT) + i * 16 + frow, k2 * 4 + fq));
+        for (int i = 0; i < WNT; ++i) {
+          const int off = lds_off(wn * (16 * WNT) + i * 16 + frow, ks * 4 + fq);
+          wf[i] = *reinterpret_cast<const bf16x8*>(ws + off);
+          if constexpr (NS == 2) wl[i] = *reinterpret_cast<const bf16x8*>(ws + WS_BYTES + off);
+        }
 #pragma unroll
         for (int i = 0; i < WNT; ++i)
 #pragma unroll
-          for (int j = 0; j < WMT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < WMT; ++j) {
+            if constexpr (NS == 2) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xf[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xl[j], acc[i][j], 0, 0, 0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          }
       }
       wbuf ^= 1;
     }
+  }
+  if constexpr (KG == 2) {
+    // fold the second k-group's partial tile into the first: [wave & 3][i][j][lane] f32x4 in the (now idle) weight ring / row buffers
+    static_assert(KG == 1 || 4 * WNT * WMT * 64 * 16 <= 2 * NS * WS_BYTES + 2 * NS * 17 * 1024, "reduction buffer must fit in the block's LDS");
+    __syncthreads();  // every wave is done reading (all DMA was retired by the last vmcnt(0))
+    f32x4* red = reinterpret_cast<f32x4*>(smem) + ((wave & 3) * WNT * WMT) * 64 + lane;
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < WNT; ++i)
+#pragma unroll
+        for (int j = 0; j < WMT; ++j) red[(i * WMT + j) * 64] = acc[i][j];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int i = 0; i < WNT; ++i)
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) acc[i][j] += red[(i * WMT + j) * 64];
   }
   if constexpr (PAIR) {
     gemm_epilogue_pairs<WNT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, bz, r2, r1, pre_res, bpre, pre_bias);
@@ -1176,7 +1228,7 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     if (knob && p.rowhalo && batch == 1 && p.splits <= ngroups) {
       halo = true;
       kern = p.pair ? conv3_rowhalo_kernel<WNT, YT, true> : conv3_rowhalo_kernel<WNT, YT, false>;
-      const int R = 128 / p.W, XP = (R * (p.W + 2) + 7) / 8;
+      const int XP = p.W > 128 ? 17 : ((128 / p.W) * (p.W + 2) + 7) / 8;
       lds_bytes = (size_t)2 * BN * 128 + (size_t)2 * XP * 1024;
       p.ks_q = ngroups / p.splits;  // K slices in (chunk, kernel row) groups
       p.ks_r = ngroups % p.splits;
@@ -1310,19 +1362,33 @@ int launch_planes(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   p.tile_count = p.tiles_n * p.tiles_m;
   p.slab_row0 = 0;
   void (*kern)(GemmP) = gemm_glds_kernel<WNT, float, CONV, 2, 4, 2, 2>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", lds, hipGetErrorString(e));
-    attr_set = true;
+  size_t lds_bytes = lds;
+  int units = (p.K + BK - 1) / BK;  // K slices in k-tiles ...
+  bool halo = false;
+  if constexpr (CONV && (WNT == 4 || WNT == 5)) {
+    static const int knob = getenv("CRG_ROWHALO") ? atoi(getenv("CRG_ROWHALO")) : 1;  // dev knob: 0 = plain implicit GEMM
+    const int ngroups = (p.K / BK) / 3;
+    if (knob && p.rowhalo && batch == 1 && p.splits <= ngroups) {
+      halo = true;
+      kern = conv3_rowhalo_kernel<WNT, float, false, 2, 2>;
+      const int XP = p.W > 128 ? 17 : ((128 / p.W) * (p.W + 2) + 7) / 8;
+      lds_bytes = (size_t)2 * 2 * BN * 128 + (size_t)2 * 2 * XP * 1024;
+      units = ngroups;  // ... or in (chunk, kernel row) groups
+    }
+  }
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[halo]) {
+    const size_t cap = halo ? (size_t)(2 * 2 * BN * 128 + 2 * 2 * 18 * 1024) : lds;  // eligible widths need <= 18 pieces per row buffer
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+    if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", cap, hipGetErrorString(e));
+    attr_set[halo] = true;
   }
   {
-    const int nk_total = (p.K + BK - 1) / BK;
-    p.ks_q = nk_total / p.splits;
-    p.ks_r = nk_total % p.splits;
+    p.ks_q = units / p.splits;
+    p.ks_r = units % p.splits;
     p.pair = 0;
     crg_prof_scope ps(ctx, st, CONV ? CRG_K_CONV_X3 : CRG_K_GEMM_X3, wk.flops, wk.bytes);
-    hipLaunchKernelGGL(kern, dim3(p.tiles_n * p.tiles_m * p.splits, batch, 1), dim3(512), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_n * p.tiles_m * p.splits, batch, 1), dim3(512), lds_bytes, st, p);
     CRG_CHECK_LAUNCH(ctx, "gemm(planes)");
   }
   if (p.splits > 1) {
@@ -1425,8 +1491,9 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
   p.pad_t = a->pad_t; p.pad_l = a->pad_l; p.up = a->upsample2x;
   p.cm = (a->ksize == 3 && Ctot % 64 == 0) ? 1 : 0;  // must match crg_pack_weight's layout rule
   p.rowhalo = (p.cm && a->stride == 1 && !a->upsample2x && a->pad_t == 1 && a->pad_l == 1 && a->Ho == a->H && a->Wo == a->W &&
-               a->W >= 16 && a->W <= 128 && 128 % a->W == 0 && a->C1 % 8 == 0 && a->x_dtype == CRG_BF16 && a->y_dtype == CRG_BF16 &&
-               a->prec == CRG_PREC_BF16) ? 1 : 0;
+               a->W >= 16 && (a->W <= 128 ? 128 % a->W == 0 : a->W % 128 == 0) && a->C1 % 8 == 0 && a->x_dtype == CRG_BF16 &&
+               ((a->y_dtype == CRG_BF16 && a->prec == CRG_PREC_BF16) || (a->y_dtype == CRG_F32 && a->prec == CRG_PREC_BF16X3 && a->x_lo)))
+                  ? 1 : 0;
   const double flops = 2.0 * p.M * (double)p.N * p.K;
   const double bytes = (double)a->N * a->H * a->W * Ctot * crg_dtype_size(a->x_dtype) + (double)p.N * p.K * 2 +
                        (double)p.M * p.N * crg_dtype_size(a->y_dtype) * (a->residual ? 2 : 1);

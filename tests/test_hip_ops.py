@@ -235,6 +235,23 @@ def test_conv_rowhalo_shapes(N, C1, C2, H, W, Co):
         check(got, ref, BF, f"rowhalo conv {N}x{C1}+{C2}x{H}x{W}->{Co} {sorted(kw)}")
 
 
+@pytest.mark.parametrize("N,C,H,W,Co", [(1, 64, 16, 16, 64), (2, 128, 8, 32, 128), (1, 128, 6, 256, 96), (1, 256, 16, 64, 160),
+                                          (1, 64, 3, 128, 64), (3, 64, 5, 16, 32)])
+def test_conv_rowhalo_planes(N, C, H, W, Co):
+    """The fp32-class (split-plane) form of the row-halo conv, incl. 128-pixel row segments of wider images, against fp64."""
+    from cremage_amd import ops
+    x = rnd(N, C, H, W, seed=90, scale=2.0) + 0.5
+    w, b = rnd(Co, C, 3, 3, seed=91, scale=(9 * C) ** -0.5), rnd(Co, seed=92)
+    res = rnd(N, Co, H, W, seed=93)
+    hi, lo = ops.split_bf16(nhwc(x, torch.float32))
+    for with_res in (False, True):
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + (res.double() if with_res else 0.0)
+        got = ops.conv2d(hi, w.to(_dev()), b.to(_dev()), x_lo=lo, residual=nhwc(res, torch.float32) if with_res else None)
+        assert got.dtype == torch.float32
+        err = (got.double().cpu() - ref).abs().max().item()
+        assert err < 3e-5 * max(1.0, ref.abs().max().item()), (N, C, H, W, Co, with_res, err)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_unet_shapes(dtype):
     """production channel counts at small spatial size (tile tails in both M and N)"""
