@@ -854,15 +854,19 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
 // fragment pair; 132 KB, one block per CU like the 4-plane kernel it replaces, but 43 instead of 64 KB staged per k-tile.
 // Widths that are multiples of 128 (VAE levels 128..512) use one row SEGMENT of 128 pixels per tile (R = 1, halo = the
 // neighbouring pixels of the same row).
-template <int WNT, typename YT, bool PAIR, int NS = 1, int KG = 1>
-__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3_rowhalo_kernel(GemmP p) {
+// MT = 2: 256-row tiles on eight waves (4 x 2), one block per CU: the weight k-tile is staged once per 256 rows (31 KB per
+// k-tile and 256 x BN outputs instead of 2 x 26 KB).
+template <int WNT, typename YT, bool PAIR, int NS = 1, int KG = 1, int MT = 1>
+__global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void conv3_rowhalo_kernel(GemmP p) {
   static_assert(!PAIR || (sizeof(YT) == 2 && NS == 1), "paired columns: bf16 output, single-plane operands");
-  constexpr int WMT = 4, NW = 4 * KG;
+  static_assert(MT == 1 || (KG == 1 && NS == 1), "256-row tiles: single-plane operands, no in-block split-K");
+  constexpr int WMT = 4, NW = 4 * KG * MT;
+  constexpr int TP = 128 * MT;  // tile pixels
   constexpr int BN = 32 * WNT;
   constexpr int WS_BYTES = BN * 128;
   constexpr int WRG = BN / 8;
   constexpr int WL = (WRG + NW - 1) / NW;
-  constexpr int XI = (20 + NW - 1) / NW;  // row-buffer pieces (8 pixels = 1 KiB) per wave, group and plane: 128 + 2 R <= 160 pixels = 20 pieces
+  constexpr int XI = ((MT == 2 ? 36 : 20) + NW - 1) / NW;  // row-buffer pieces (8 pixels = 1 KiB) per wave, group and plane: TP + 2 R pixels, W >= 16
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -870,12 +874,12 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3_rowhalo_kerne
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int kg = wave >> 2;
-  const int wm = (wave & 3) >> 1, wn = wave & 1;
+  const int kg = MT == 2 ? 0 : wave >> 2;
+  const int wm = MT == 2 ? wave >> 1 : (wave & 3) >> 1, wn = wave & 1;
   const int Wd = p.W;
-  const bool seg = Wd > 128;             // tile = 128-pixel segment of one image row
-  const int WP = seg ? 130 : Wd + 2;
-  const int R = seg ? 1 : 128 / Wd;
+  const bool seg = Wd > TP;              // tile = TP-pixel segment of one image row
+  const int WP = seg ? TP + 2 : Wd + 2;
+  const int R = seg ? 1 : TP / Wd;
   const int xpix = R * WP;
   const int XP = (xpix + 7) >> 3;
   const int xbuf_bytes = XP * 1024;      // one plane of one row buffer
@@ -884,7 +888,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3_rowhalo_kerne
 
   int tile_m, tile_n, sid;
   block_to_tile(p, tile_m, tile_n, sid);
-  const int m0 = tile_m * 128, n0 = tile_n * BN;
+  const int m0 = tile_m * TP, n0 = tile_n * BN;
   const int bz = 0;
   const bf16* Wp = p.w;
   const long a_lo_off = NS == 2 ? reinterpret_cast<const bf16*>(p.a_lo) - reinterpret_cast<const bf16*>(p.a) : 0;
@@ -1222,31 +1226,39 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   else kern = gemm_kernel<WNT, NSPLIT, AT, YT, CONV, NSPLIT>;  // split-bf16: 8 waves (two k-groups)
   size_t lds_bytes = lds;
   bool halo = false;
+  int threads = GLDS ? 256 * KG : 256 * NSPLIT;
   if constexpr (GLDS && CONV && STAGES == 2 && WMT == 4 && KG == 1 && sizeof(YT) == 2 && (WNT == 4 || WNT == 5)) {
-    static const int knob = getenv("CRG_ROWHALO") ? atoi(getenv("CRG_ROWHALO")) : 1;  // dev knob: 0 = plain implicit GEMM
+    static const int knob = getenv("CRG_ROWHALO") ? atoi(getenv("CRG_ROWHALO")) : 2;  // dev knob: 0 = plain implicit GEMM
     const int ngroups = (p.K / BK) / 3;
     if (knob && p.rowhalo && batch == 1 && p.splits <= ngroups) {
       halo = true;
-      kern = p.pair ? conv3_rowhalo_kernel<WNT, YT, true> : conv3_rowhalo_kernel<WNT, YT, false>;
-      const int XP = p.W > 128 ? 17 : ((128 / p.W) * (p.W + 2) + 7) / 8;
+      const int TP = p.rowhalo == 2 ? 256 : 128;
+      if (p.rowhalo == 2) {
+        kern = p.pair ? conv3_rowhalo_kernel<WNT, YT, true, 1, 1, 2> : conv3_rowhalo_kernel<WNT, YT, false, 1, 1, 2>;
+        threads = 512;
+      } else {
+        kern = p.pair ? conv3_rowhalo_kernel<WNT, YT, true> : conv3_rowhalo_kernel<WNT, YT, false>;
+      }
+      const int XP = p.W > TP ? (TP + 2 + 7) / 8 : ((TP / p.W) * (p.W + 2) + 7) / 8;
       lds_bytes = (size_t)2 * BN * 128 + (size_t)2 * XP * 1024;
       p.ks_q = ngroups / p.splits;  // K slices in (chunk, kernel row) groups
       p.ks_r = ngroups % p.splits;
     }
   }
-  static bool attr_set[4] = {false, false, false, false};
-  if (!attr_set[p.pair + 2 * halo]) {
-    const size_t cap = halo ? (size_t)80 * 1024 : lds;
+  static bool attr_set[6] = {false, false, false, false, false, false};
+  const int ai = p.pair + 2 * (halo ? (p.rowhalo == 2 ? 2 : 1) : 0);
+  if (!attr_set[ai]) {
+    const size_t cap = halo ? (size_t)(p.rowhalo == 2 ? 116 : 80) * 1024 : lds;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
     if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", cap, hipGetErrorString(e));
-    attr_set[p.pair + 2 * halo] = true;
+    attr_set[ai] = true;
   }
   dim3 grid(p.tile_count * p.splits, batch, 1);
   constexpr int slot = !GLDS ? (CONV ? CRG_K_CONV_X3 : CRG_K_GEMM_X3)
                              : (CONV ? (WNT == 5 ? CRG_K_CONV_W5 : WNT == 4 ? CRG_K_CONV_W4 : CRG_K_CONV_W1)
                                      : (WNT == 5 ? CRG_K_GEMM_W5 : WNT == 4 ? CRG_K_GEMM_W4 : CRG_K_GEMM_W1));
   crg_prof_scope ps(ctx, st, slot, wk.flops, wk.bytes);
-  hipLaunchKernelGGL(kern, grid, dim3(GLDS ? 256 * KG : 256 * NSPLIT), lds_bytes, st, p);
+  hipLaunchKernelGGL(kern, grid, dim3(threads), lds_bytes, st, p);
   CRG_CHECK_LAUNCH(ctx, "gemm");
   return 0;
 }
@@ -1281,6 +1293,16 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     p.tiles_m = (p.M + 63) / 64;
     p.splits = force ? choose_splits(p, p.tiles_n * p.tiles_m, batch) : 1;
   }
+  if constexpr (GLDS && CONV && sizeof(YT) == 2 && (WNT == 4 || WNT == 5)) {
+    // row-halo conv on 256-row tiles (one 8-wave block per CU): same K slices, half the m-tiles
+    static const int knob = getenv("CRG_ROWHALO") ? atoi(getenv("CRG_ROWHALO")) : 2;  // dev knob: 0 plain implicit GEMM, 1 128-row tiles only
+    const int ngroups = (p.K / BK) / 3;
+    if (knob == 2 && cfg == 1 && p.rowhalo && batch == 1 && p.splits <= ngroups && p.M % 256 == 0 &&
+        (p.W <= 256 ? 256 % p.W == 0 : p.W % 256 == 0)) {
+      p.rowhalo = 2;
+      p.tiles_m = p.M / 256;
+    }
+  }
   if (p.splits > 1) {
     p.slab = (float*)crg_scratch(ctx, (size_t)batch * p.splits * p.M * p.N * sizeof(float));
     if (!p.slab) return crg_fail(ctx, -12, "gemm: out of scratch for %d split-K slabs", p.splits);
@@ -1297,7 +1319,7 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     // fill the chip once more for a fraction of a round, and are summed by the split-K reduce over just their rows.
     const int T = p.tile_count, nk = (p.K + BK - 1) / BK;
     const int r = T % 512, T1 = T - r;
-    if (cfg == 1 && p.splits == 1 && batch == 1 && T1 >= 512 && r > 0 && r <= 224 && nk >= 16 && r % p.tiles_n == 0 &&
+    if (cfg == 1 && p.rowhalo != 2 && p.splits == 1 && batch == 1 && T1 >= 512 && r > 0 && r <= 224 && nk >= 16 && r % p.tiles_n == 0 &&
         p.epi != CRG_EPI_GEGLU && !(p.N & 3)) {
       int s2 = 512 / r;
       if (s2 > nk / 4) s2 = nk / 4;
