@@ -45,6 +45,11 @@ def slot_of(name):
         if ns == "2":  # the split-plane fp32-class variant is accounted in the x3 slots
             return "conv_x3" if conv else "gemm_x3"
         return ("conv_w" if conv else "gemm_w") + wnt
+    # conv3_rowhalo_kernel<WNT, YT, PAIR, NS, KG, MT>
+    m = re.search(r"conv3_rowhalo_kernelILi(\d)E(?:DF16b|DF16_|f)Lb[01]ELi(\d+)E", name) or \
+        re.search(r"conv3_rowhalo_kernel<(\d), (?:bool _Accum, bool, E|[\w ]+, (?:true|false)), (\d+),", name)
+    if m:
+        return "conv_x3" if m.group(2) == "2" else "conv_w" + m.group(1)
     if "gemm_kernel" in name:
         return "conv_x3" if (("Lb1E" in name) or re.search(r", true[,>]", name)) else "gemm_x3"
     for pat, slot in (("splitk_reduce", "splitk_reduce"), ("attn_kernel", "attention"), ("gn_stats", "gn_stats"), ("gn_apply", "gn_apply"), ("gn_small", "gn_apply"),
