@@ -42,7 +42,8 @@ struct GemmP {
   // of the n-fastest tile order; the split-K slab then only holds rows >= slab_row0
   int tile_base, tile_count, slab_row0;
   int pair;        // paired-column output mapping (see unpair_col): 16-byte epilogue accesses
-  int rowhalo;     // conv: eligible for conv3_rowhalo_kernel (3x3, stride 1, pad 1, chunk-major K, image width divides 128)
+  int rowhalo;     // conv: eligible for conv3_rowhalo_kernel (3x3, stride 1, pad 1, chunk-major K); 2 = on 256-row tiles
+  int halo_lin;    // ... with the linear-pixel row buffer (widths that neither divide the tile nor are a multiple of it)
   int ks_q, ks_r;  // k-tiles per K-slice: nk_total = splits * ks_q + ks_r
   int xg_m, xg_n, xg_s;  // XCD partition of the (m-tile, n-tile, k-slice) grid, product 8; xg_s == 0: legacy contiguous order
 };
@@ -877,7 +878,11 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
   const int kg = MT == 2 ? 0 : wave >> 2;
   const int wm = MT == 2 ? wave >> 1 : (wave & 3) >> 1, wn = wave & 1;
   const int Wd = p.W;
-  const bool seg = Wd > TP;              // tile = TP-pixel segment of one image row
+  // three buffer geometries: rows (W divides the tile: R whole image rows, each with a zero / neighbour pixel left and right),
+  // seg (W a multiple of the tile: one row segment) and lin (any other width: the TP + 2 pixels m0 - 1 .. m0 + TP in linear
+  // pixel order; a tap that would wrap around an image row is zeroed in the A fragment instead of in the buffer)
+  const bool lin = p.halo_lin != 0;
+  const bool seg = lin || Wd > TP;       // lin shares seg's addressing: buffer pixel b <-> linear pixel m0 - 1 + b
   const int WP = seg ? TP + 2 : Wd + 2;
   const int R = seg ? 1 : TP / Wd;
   const int xpix = R * WP;
@@ -907,11 +912,20 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const int b = 8 * (wave + NW * i) + rsub;
-      const int r = b / WP, col = b - r * WP;
-      const int grow = row0 + r;
+      int grow, w;
+      bool ok;
+      if (lin) {
+        const int pb = m0 - 1 + b;  // the pixel whose (kh - 1)-th row neighbour this buffer pixel holds
+        ok = b < xpix && pb >= 0 && pb < p.M;
+        grow = (pb < 0 ? 0 : pb) / Wd;
+        w = pb - grow * Wd;
+      } else {
+        const int r = b / WP, col = b - r * WP;
+        grow = row0 + r;
+        w = w0 + col - 1;
+        ok = b < xpix && grow < rows_total && w >= 0 && w < Wd;
+      }
       const int img = grow / p.H, h = grow - img * p.H;
-      const int w = w0 + col - 1;
-      const bool ok = b < xpix && grow < rows_total && w >= 0 && w < Wd;
       unsigned msk = 0;
       if (ok) msk = (h >= 1 ? 1u : 0u) | 2u | (h + 1 < p.H ? 4u : 0u);
       xmask[i] = msk;
@@ -986,6 +1000,17 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
     const int r = seg ? 0 : ml / Wd;
     xb0[j] = r * WP + (ml - r * Wd);
   }
+  // lin: output pixels in the first / last image column must not see the wrapped neighbour (taps kw = 0 / kw = 2)
+  unsigned edge = 0;  // bit j: first column, bit 8 + j: last column
+  if (lin) {
+#pragma unroll
+    for (int j = 0; j < WMT; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + frow;
+      const int wcol = m % Wd;
+      edge |= (wcol == 0 ? 1u : 0u) << j;
+      edge |= (wcol == Wd - 1 ? 1u : 0u) << (8 + j);
+    }
+  }
 
   // residual / bias prefetch: as in gemm_glds_kernel (unconditional loads on clamped addresses)
   bf16x4 rres[PAIR ? 1 : WNT][PAIR ? 1 : WMT];
@@ -1059,6 +1084,15 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
           const int off = lds_off(xb0[j] + kw, ks * 4 + fq);
           xf[j] = *reinterpret_cast<const bf16x8*>(xs + off);
           if constexpr (NS == 2) xl[j] = *reinterpret_cast<const bf16x8*>(xs + xbuf_bytes + off);
+        }
+        if (kw != 1 && lin) {  // block-uniform branch: nothing on the hot path of the other geometries
+#pragma unroll
+          for (int j = 0; j < WMT; ++j) {
+            if ((edge >> (kw == 0 ? j : 8 + j)) & 1u) {
+              xf[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+              if constexpr (NS == 2) xl[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+          }
         }
 #pragma unroll
         for (int i = 0; i < WNT; ++i) {
@@ -1239,7 +1273,7 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
       } else {
         kern = p.pair ? conv3_rowhalo_kernel<WNT, YT, true> : conv3_rowhalo_kernel<WNT, YT, false>;
       }
-      const int XP = p.W > TP ? (TP + 2 + 7) / 8 : ((TP / p.W) * (p.W + 2) + 7) / 8;
+      const int XP = (p.halo_lin || p.W > TP) ? (TP + 2 + 7) / 8 : ((TP / p.W) * (p.W + 2) + 7) / 8;
       lds_bytes = (size_t)2 * BN * 128 + (size_t)2 * XP * 1024;
       p.ks_q = ngroups / p.splits;  // K slices in (chunk, kernel row) groups
       p.ks_r = ngroups % p.splits;
@@ -1298,9 +1332,14 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     static const int knob = getenv("CRG_ROWHALO") ? atoi(getenv("CRG_ROWHALO")) : 2;  // dev knob: 0 plain implicit GEMM, 1 128-row tiles only
     const int ngroups = (p.K / BK) / 3;
     if (knob == 2 && cfg == 1 && p.rowhalo && batch == 1 && p.splits <= ngroups && p.M % 256 == 0 &&
-        (p.W <= 256 ? 256 % p.W == 0 : p.W % 256 == 0)) {
-      p.rowhalo = 2;
-      p.tiles_m = p.M / 256;
+        (p.halo_lin || (p.W <= 256 ? 256 % p.W == 0 : p.W % 256 == 0))) {
+      // one block per CU: only when the grid fills its rounds of 256 blocks (a 288-block grid would run a second round 1/8 full)
+      const long blocks2 = (long)(p.M / 256) * p.tiles_n * p.splits;
+      const long rounds = (blocks2 + 255) / 256;
+      if (blocks2 * 100 >= rounds * 256 * 85) {
+        p.rowhalo = 2;
+        p.tiles_m = p.M / 256;
+      }
     }
   }
   if (p.splits > 1) {
@@ -1393,7 +1432,7 @@ int launch_planes(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     if (knob && p.rowhalo && batch == 1 && p.splits <= ngroups) {
       halo = true;
       kern = conv3_rowhalo_kernel<WNT, float, false, 2, 2>;
-      const int XP = p.W > 128 ? 17 : ((128 / p.W) * (p.W + 2) + 7) / 8;
+      const int XP = (p.halo_lin || p.W > 128) ? 17 : ((128 / p.W) * (p.W + 2) + 7) / 8;
       lds_bytes = (size_t)2 * 2 * BN * 128 + (size_t)2 * 2 * XP * 1024;
       units = ngroups;  // ... or in (chunk, kernel row) groups
     }
@@ -1513,9 +1552,10 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
   p.pad_t = a->pad_t; p.pad_l = a->pad_l; p.up = a->upsample2x;
   p.cm = (a->ksize == 3 && Ctot % 64 == 0) ? 1 : 0;  // must match crg_pack_weight's layout rule
   p.rowhalo = (p.cm && a->stride == 1 && !a->upsample2x && a->pad_t == 1 && a->pad_l == 1 && a->Ho == a->H && a->Wo == a->W &&
-               a->W >= 16 && (a->W <= 128 ? 128 % a->W == 0 : a->W % 128 == 0) && a->C1 % 8 == 0 && a->x_dtype == CRG_BF16 &&
+               a->C1 % 8 == 0 && a->x_dtype == CRG_BF16 &&
                ((a->y_dtype == CRG_BF16 && a->prec == CRG_PREC_BF16) || (a->y_dtype == CRG_F32 && a->prec == CRG_PREC_BF16X3 && a->x_lo)))
                   ? 1 : 0;
+  p.halo_lin = (a->W >= 16 && (a->W <= 128 ? 128 % a->W == 0 : a->W % 128 == 0)) ? 0 : 1;
   const double flops = 2.0 * p.M * (double)p.N * p.K;
   const double bytes = (double)a->N * a->H * a->W * Ctot * crg_dtype_size(a->x_dtype) + (double)p.N * p.K * 2 +
                        (double)p.M * p.N * crg_dtype_size(a->y_dtype) * (a->residual ? 2 : 1);

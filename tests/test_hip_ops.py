@@ -218,6 +218,11 @@ def test_split_planes_path(C, Co, ks):
     (1, 64, 0, 4, 128, 64),       # one image row per tile
     (2, 320, 0, 64, 64, 320),     # production shape (SD1.5 64x64 level)
     (8, 640, 0, 32, 32, 640),     # production shape: 256 tiles -> two K slices
+    (2, 64, 0, 9, 7, 64),         # linear-pixel row buffer: width 7, M = 126 (one partial tile)
+    (2, 128, 64, 24, 40, 96),     # linear: ragged latent, concat
+    (1, 320, 0, 96, 96, 320),     # linear: 768x768 image level (C4), 256-row tiles
+    (3, 64, 0, 8, 8, 64),         # linear: 8x8 level, tiles straddling images
+    (1, 64, 0, 2, 200, 64),       # linear: rows longer than a tile
 ])
 def test_conv_rowhalo_shapes(N, C1, C2, H, W, Co):
     """3x3 / stride 1 / pad 1 convs whose width divides 128 run on conv3_rowhalo_kernel (one halo'd row buffer per kernel row
@@ -236,7 +241,7 @@ def test_conv_rowhalo_shapes(N, C1, C2, H, W, Co):
 
 
 @pytest.mark.parametrize("N,C,H,W,Co", [(1, 64, 16, 16, 64), (2, 128, 8, 32, 128), (1, 128, 6, 256, 96), (1, 256, 16, 64, 160),
-                                          (1, 64, 3, 128, 64), (3, 64, 5, 16, 32)])
+                                          (1, 64, 3, 128, 64), (3, 64, 5, 16, 32), (2, 64, 24, 20, 96), (1, 128, 5, 96, 128)])
 def test_conv_rowhalo_planes(N, C, H, W, Co):
     """The fp32-class (split-plane) form of the row-halo conv, incl. 128-pixel row segments of wider images, against fp64."""
     from cremage_amd import ops
