@@ -877,7 +877,8 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int kg = MT == 2 ? 0 : wave >> 2;
   const int wm = MT == 2 ? wave >> 1 : (wave & 3) >> 1, wn = wave & 1;
-  const int Wd = p.W;
+  // geometry lives on the OUTPUT grid (Ho x Wo; the nearest-2x upsampled image when p.up), sources are read at (h >> up, w >> up)
+  const int Wd = p.Wo, Hd = p.Ho, sh = p.up ? 1 : 0;
   // three buffer geometries: rows (W divides the tile: R whole image rows, each with a zero / neighbour pixel left and right),
   // seg (W a multiple of the tile: one row segment) and lin (any other width: the TP + 2 pixels m0 - 1 .. m0 + TP in linear
   // pixel order; a tap that would wrap around an image row is zeroed in the A fragment instead of in the buffer)
@@ -903,8 +904,9 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
   const int clog = (lane & 7) ^ rsub;
 
   // row-buffer pieces of this lane: piece jp = wave + NW i covers buffer pixels 8 jp .. 8 jp + 7, this lane pixel 8 jp + rsub
-  int xsrc[XI];        // source pixel index (kernel row kh = 1), valid when a mask bit is set
-  unsigned xmask[XI];  // bit kh: source row h + kh - 1 inside the image (and pixel inside the tile / image / problem)
+  int xsrc[XI];        // source pixel index of (image, row 0, column w >> up), valid when a mask bit is set
+  int xh[XI];          // output-grid row h of the buffer pixel: kernel row kh reads source row (h + kh - 1) >> up
+  unsigned xmask[XI];  // bit kh: row h + kh - 1 inside the image (and pixel inside the tile / image / problem)
   {
     const int rows_total = p.M / Wd;  // N * H image rows
     const int row0 = m0 / Wd;
@@ -925,11 +927,12 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
         w = w0 + col - 1;
         ok = b < xpix && grow < rows_total && w >= 0 && w < Wd;
       }
-      const int img = grow / p.H, h = grow - img * p.H;
+      const int img = grow / Hd, h = grow - img * Hd;
       unsigned msk = 0;
-      if (ok) msk = (h >= 1 ? 1u : 0u) | 2u | (h + 1 < p.H ? 4u : 0u);
+      if (ok) msk = (h >= 1 ? 1u : 0u) | 2u | (h + 1 < Hd ? 4u : 0u);
       xmask[i] = msk;
-      xsrc[i] = grow * Wd + w;
+      xh[i] = h;
+      xsrc[i] = img * p.H * p.W + (w >> sh);
     }
   }
   bool wok[WL];
@@ -959,7 +962,7 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
       const int jp = wave + NW * i;
       if (jp < XP) {  // wave-uniform
         const bool ok = (xmask[i] >> kh) & 1u;
-        const bf16* src = ok ? base + (long)(xsrc[i] + (kh - 1) * Wd) * Cs + cs : zpage;
+        const bf16* src = ok ? base + (long)(xsrc[i] + ((xh[i] + kh - 1) >> sh) * p.W) * Cs + cs : zpage;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xb + jp * 1024), 16, 0, 0);
         if constexpr (NS == 2) {
           const bf16* src2 = ok ? src + a_lo_off : zpage;
@@ -1273,7 +1276,7 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
       } else {
         kern = p.pair ? conv3_rowhalo_kernel<WNT, YT, true> : conv3_rowhalo_kernel<WNT, YT, false>;
       }
-      const int XP = (p.halo_lin || p.W > TP) ? (TP + 2 + 7) / 8 : ((TP / p.W) * (p.W + 2) + 7) / 8;
+      const int XP = (p.halo_lin || p.Wo > TP) ? (TP + 2 + 7) / 8 : ((TP / p.Wo) * (p.Wo + 2) + 7) / 8;
       lds_bytes = (size_t)2 * BN * 128 + (size_t)2 * XP * 1024;
       p.ks_q = ngroups / p.splits;  // K slices in (chunk, kernel row) groups
       p.ks_r = ngroups % p.splits;
@@ -1332,7 +1335,7 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     static const int knob = getenv("CRG_ROWHALO") ? atoi(getenv("CRG_ROWHALO")) : 2;  // dev knob: 0 plain implicit GEMM, 1 128-row tiles only
     const int ngroups = (p.K / BK) / 3;
     if (knob == 2 && cfg == 1 && p.rowhalo && batch == 1 && p.splits <= ngroups && p.M % 256 == 0 &&
-        (p.halo_lin || (p.W <= 256 ? 256 % p.W == 0 : p.W % 256 == 0))) {
+        (p.halo_lin || (p.Wo <= 256 ? 256 % p.Wo == 0 : p.Wo % 256 == 0))) {
       // one block per CU: only when the grid fills its rounds of 256 blocks (a 288-block grid would run a second round 1/8 full)
       const long blocks2 = (long)(p.M / 256) * p.tiles_n * p.splits;
       const long rounds = (blocks2 + 255) / 256;
@@ -1432,7 +1435,7 @@ int launch_planes(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     if (knob && p.rowhalo && batch == 1 && p.splits <= ngroups) {
       halo = true;
       kern = conv3_rowhalo_kernel<WNT, float, false, 2, 2>;
-      const int XP = (p.halo_lin || p.W > 128) ? 17 : ((128 / p.W) * (p.W + 2) + 7) / 8;
+      const int XP = (p.halo_lin || p.Wo > 128) ? 17 : ((128 / p.Wo) * (p.Wo + 2) + 7) / 8;
       lds_bytes = (size_t)2 * 2 * BN * 128 + (size_t)2 * 2 * XP * 1024;
       units = ngroups;  // ... or in (chunk, kernel row) groups
     }
@@ -1551,11 +1554,11 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
   p.H = a->H; p.W = a->W; p.Ho = a->Ho; p.Wo = a->Wo; p.ks = a->ksize; p.stride = a->stride;
   p.pad_t = a->pad_t; p.pad_l = a->pad_l; p.up = a->upsample2x;
   p.cm = (a->ksize == 3 && Ctot % 64 == 0) ? 1 : 0;  // must match crg_pack_weight's layout rule
-  p.rowhalo = (p.cm && a->stride == 1 && !a->upsample2x && a->pad_t == 1 && a->pad_l == 1 && a->Ho == a->H && a->Wo == a->W &&
+  p.rowhalo = (p.cm && a->stride == 1 && a->pad_t == 1 && a->pad_l == 1 && a->Ho == Hv && a->Wo == Wv &&
                a->C1 % 8 == 0 && a->x_dtype == CRG_BF16 &&
                ((a->y_dtype == CRG_BF16 && a->prec == CRG_PREC_BF16) || (a->y_dtype == CRG_F32 && a->prec == CRG_PREC_BF16X3 && a->x_lo)))
                   ? 1 : 0;
-  p.halo_lin = (a->W >= 16 && (a->W <= 128 ? 128 % a->W == 0 : a->W % 128 == 0)) ? 0 : 1;
+  p.halo_lin = (a->Wo >= 16 && (a->Wo <= 128 ? 128 % a->Wo == 0 : a->Wo % 128 == 0)) ? 0 : 1;  // geometry of the output grid
   const double flops = 2.0 * p.M * (double)p.N * p.K;
   const double bytes = (double)a->N * a->H * a->W * Ctot * crg_dtype_size(a->x_dtype) + (double)p.N * p.K * 2 +
                        (double)p.M * p.N * crg_dtype_size(a->y_dtype) * (a->residual ? 2 : 1);

@@ -240,6 +240,17 @@ def test_conv_rowhalo_shapes(N, C1, C2, H, W, Co):
         check(got, ref, BF, f"rowhalo conv {N}x{C1}+{C2}x{H}x{W}->{Co} {sorted(kw)}")
 
 
+@pytest.mark.parametrize("N,C,H,W,Co", [(2, 64, 8, 8, 64), (1, 128, 16, 32, 160), (1, 64, 3, 64, 64), (1, 64, 2, 128, 64), (2, 64, 5, 12, 96)])
+def test_conv_rowhalo_upsample(N, C, H, W, Co):
+    """nearest-2x upsample folded into the row-halo conv's gather (output-grid geometry, sources at (h >> 1, w >> 1)):
+    whole-row, row-segment and linear buffers."""
+    from cremage_amd import ops
+    x, w, b = rnd(N, C, H, W, seed=95), rnd(Co, C, 3, 3, seed=96, scale=(9 * C) ** -0.5), rnd(Co, seed=97)
+    ref = conv_ref(x, w, b, BF, up=True)
+    got = ops.conv2d(nhwc(x, BF), w.to(_dev()), b.to(_dev()), upsample2x=True)
+    check(got, ref, BF, f"rowhalo upsample conv {N}x{C}x{H}x{W}->{Co}")
+
+
 @pytest.mark.parametrize("N,C,H,W,Co", [(1, 64, 16, 16, 64), (2, 128, 8, 32, 128), (1, 128, 6, 256, 96), (1, 256, 16, 64, 160),
                                           (1, 64, 3, 128, 64), (3, 64, 5, 16, 32), (2, 64, 24, 20, 96), (1, 128, 5, 96, 128)])
 def test_conv_rowhalo_planes(N, C, H, W, Co):
