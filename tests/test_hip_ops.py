@@ -223,6 +223,7 @@ def test_split_planes_path(C, Co, ks):
     (1, 320, 0, 96, 96, 320),     # linear: 768x768 image level (C4), 256-row tiles
     (3, 64, 0, 8, 8, 64),         # linear: 8x8 level, tiles straddling images
     (1, 64, 0, 2, 200, 64),       # linear: rows longer than a tile
+    (4, 128, 0, 96, 96, 320),     # 576 tiles = 512 + 64: tail split (second launch cut along K in row groups) on the linear buffer
 ])
 def test_conv_rowhalo_shapes(N, C1, C2, H, W, Co):
     """3x3 / stride 1 / pad 1 convs whose width divides 128 run on conv3_rowhalo_kernel (one halo'd row buffer per kernel row
