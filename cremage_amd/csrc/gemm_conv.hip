@@ -17,70 +17,13 @@
 // with zero fill outside the (optionally nearest-2x-upsampled) image and a second input pointer
 // for the UNet skip concat.  BF16X3 (NSPLIT=2) stages hi and lo bf16 planes of both operands and
 // issues hi*hi + hi*lo + lo*hi.
-#include "crg_common.h"
+#include "gemm_shared.h"
 #include <cstdlib>
 
 namespace {
+using namespace crg_mm;
 
-struct GemmP {
-  const void* a; const void* a_lo; long lda, a_bs;
-  const bf16* w; const bf16* w_lo; long ldw, w_bs;
-  const float* bias; int bias_mode;
-  const void* res; long ldr, r_bs;
-  void* y; long ldy, y_bs;
-  int M, N, K, epi;
-  const float* cvec; int cvec_rows; long cvec_ld;  // cvec[(m / cvec_rows) * cvec_ld + n]
-  const bf16* zero_page;    // >= 16 bytes of zeros in device memory (LDS-DMA source for padding / tails)
-  int splits; float* slab;  // split-K: fp32 partial tiles [batch][splits][M][N], reduced by splitk_reduce_kernel
-  int a_is_weight;
-  // conv geometry
-  const void* x2; int C1, C2, Ctot, H, W, Ho, Wo, ks, stride, pad_t, pad_l, up;
-  int cm;  // conv K order: 0 = tap-major [tap][Cin]; 1 = chunk-major [Cin/64][tap][64] (consecutive k-tiles re-read the
-           // same 64-channel slab of neighbouring pixels -> the 9 taps hit in L1 instead of going back to L2)
-  int tiles_n, tiles_m;
-  // partial launches (tail of a grid that does not fill whole rounds, see launch()): tiles [tile_base, tile_base + tile_count)
-  // of the n-fastest tile order; the split-K slab then only holds rows >= slab_row0
-  int tile_base, tile_count, slab_row0;
-  int pair;        // paired-column output mapping (see unpair_col): 16-byte epilogue accesses
-  int rowhalo;     // conv: eligible for conv3_rowhalo_kernel (3x3, stride 1, pad 1, chunk-major K); 2 = on 256-row tiles
-  int halo_lin;    // ... with the linear-pixel row buffer (widths that neither divide the tile nor are a multiple of it)
-  int ks_q, ks_r;  // k-tiles per K-slice: nk_total = splits * ks_q + ks_r
-  int xg_m, xg_n, xg_s;  // XCD partition of the (m-tile, n-tile, k-slice) grid, product 8; xg_s == 0: legacy contiguous order
-};
 
-constexpr int BM = 128;
-constexpr int BK = 64;
-
-// Block -> (m-tile, n-tile, k-slice).  The dispatcher deals workgroups round-robin to the 8 XCDs (block L runs on XCD
-// L % 8) and every XCD has its own 4 MB L2, so whatever two XCDs both touch is fetched twice over the fabric.  The host
-// picks a partition (xg_m x xg_n x xg_s = 8) of the tile grid that minimises xg_n * |A| + xg_m * |W| (k-slices share
-// nothing, so cutting along split-K is free): activation-heavy shapes (64x64 levels) give every XCD a contiguous run of
-// m-tiles and the whole small W, weight-heavy shapes (8x8 / 16x16 levels, 1280-wide) give every XCD its own slice of W.
-// Inside an XCD the order is n fastest, then m, then k-slice, so co-resident blocks share A rows and W panels.
-__device__ __forceinline__ void block_to_tile(const GemmP& p, int& tile_m, int& tile_n, int& sid) {
-  const int L = blockIdx.x;
-  if (p.xg_s) {
-    const int xcd = L & 7, idx = L >> 3;
-    const int xs = xcd % p.xg_s, xr = xcd / p.xg_s;
-    const int xn = xr % p.xg_n, xm = xr / p.xg_n;
-    const int nnl = p.tiles_n / p.xg_n, nml = p.tiles_m / p.xg_m, nsl = p.splits / p.xg_s;
-    const int tn = idx % nnl, r = idx / nnl;
-    const int tm = r % nml, ts = r / nml;
-    tile_n = xn * nnl + tn;
-    tile_m = xm * nml + tm;
-    sid = xs * nsl + ts;
-  } else {  // tile counts not divisible: contiguous runs of tiles per XCD (bijective for any count)
-    const int T = p.tile_count;
-    sid = L / T;
-    int bid = L - sid * T;
-    const int q = T >> 3, r = T & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3) + p.tile_base;
-    tile_n = bid % p.tiles_n;
-    tile_m = bid / p.tiles_n;
-  }
-}
-
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
 __device__ __forceinline__ bf16x8 split_hi(const crg_vec8<float>& v, bf16x8& lo) {
   bf16x8 hi;
@@ -94,200 +37,6 @@ __device__ __forceinline__ bf16x8 split_hi(const crg_vec8<float>& v, bf16x8& lo)
   return hi;
 }
 
-// ---- shared epilogue: lane holds rows n = ..+fq*4+{0..3}, column m = ..+frow of each 16x16 tile ----
-template <int WNT, typename YT, int WMT = 4>
-__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][WMT], int m0, int n0, int wm, int wn, int frow, int fq,
-                                              int bz, int sid, const bf16x4 (&pre)[WNT][WMT], bool use_pre,
-                                              const f32x4 (&bpre)[WNT], bool use_bpre) {
-  if (p.splits > 1) {
-    const long srows = p.M - p.slab_row0;
-    float* S = p.slab + ((long)bz * p.splits + sid) * srows * p.N - (long)p.slab_row0 * p.N;
-#pragma unroll
-    for (int j = 0; j < WMT; ++j) {
-      const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int i = 0; i < WNT; ++i) {
-        const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
-        if (n + 4 <= p.N) {
-          *reinterpret_cast<f32x4*>(S + (long)m * p.N + n) = acc[i][j];
-        } else {
-          for (int e = 0; e < 4 && n + e < p.N; ++e) S[(long)m * p.N + n + e] = acc[i][j][e];
-        }
-      }
-    }
-    return;
-  }
-  YT* Y = reinterpret_cast<YT*>(p.y) + (long)bz * p.y_bs;
-  const YT* R = p.res ? reinterpret_cast<const YT*>(p.res) + (long)bz * p.r_bs : nullptr;
-#pragma unroll
-  for (int j = 0; j < WMT; ++j) {
-    const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
-    if (m >= p.M) continue;
-    const float brow = (p.bias_mode == CRG_BIAS_ROW) ? p.bias[m] : 0.f;
-    const float* cv = p.cvec ? p.cvec + (long)(m / p.cvec_rows) * p.cvec_ld : nullptr;
-    if (p.epi == CRG_EPI_GEGLU) {
-      // packed columns: [v 16 | g 16] groups; tiles (2u, 2u+1) of this wave are value / gate
-      if constexpr (WNT % 2 == 0) {
-#pragma unroll
-        for (int u = 0; u < WNT / 2; ++u) {
-          const int pn = n0 + wn * (16 * WNT) + u * 32 + fq * 4;  // packed column of the value tile
-          if (pn >= p.N) continue;
-          const int jn = (n0 + wn * (16 * WNT)) / 2 + u * 16 + fq * 4;  // output column
-          f32x4 v = acc[2 * u][j], g = acc[2 * u + 1][j];
-          if (p.bias_mode == CRG_BIAS_COL) {
-            v += *reinterpret_cast<const f32x4*>(p.bias + pn);
-            g += *reinterpret_cast<const f32x4*>(p.bias + pn + 16);
-          }
-          YT out[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) out[e] = (YT)(v[e] * crg_gelu_erf_f(g[e]));
-          YT* dst = Y + (long)m * p.ldy + jn;
-          if constexpr (sizeof(YT) == 2) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(out);
-          else *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<f32x4*>(out);
-        }
-      }
-      continue;
-    }
-#pragma unroll
-    for (int i = 0; i < WNT; ++i) {
-      const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j];
-      const bool full = (n + 4 <= p.N);
-      if (full) {
-        if (use_bpre) v += bpre[i];
-        else if (p.bias_mode == CRG_BIAS_COL) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-        else if (p.bias_mode == CRG_BIAS_ROW) v += brow;
-        if (p.epi == CRG_EPI_SILU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = crg_silu_f(v[e]);
-        }
-        if (cv) v += *reinterpret_cast<const f32x4*>(cv + n);
-        const long yo = (long)m * p.ldy + n;
-        if (use_pre) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)pre[i][j][e];
-        } else if (R) {
-          const YT* rp = R + (long)m * p.ldr + n;
-          if (((p.ldr | n) & 3) == 0) {
-            if constexpr (sizeof(YT) == 2) {
-              bf16x4 r4 = *reinterpret_cast<const bf16x4*>(rp);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
-            } else {
-              v += *reinterpret_cast<const f32x4*>(rp);
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)rp[e];
-          }
-        }
-        if (((p.ldy | n) & 3) == 0) {
-          if constexpr (sizeof(YT) == 2) {
-            bf16x4 o4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o4[e] = (bf16)v[e];
-            *reinterpret_cast<bf16x4*>(Y + yo) = o4;
-          } else {
-            *reinterpret_cast<f32x4*>(Y + yo) = v;
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) Y[yo + e] = (YT)v[e];
-        }
-      } else {
-        for (int e = 0; e < 4 && n + e < p.N; ++e) {
-          float s = v[e];
-          if (p.bias_mode == CRG_BIAS_COL) s += p.bias[n + e];
-          else if (p.bias_mode == CRG_BIAS_ROW) s += brow;
-          if (p.epi == CRG_EPI_SILU) s = crg_silu_f(s);
-          if (cv) s += cv[n + e];
-          if (R) s += (float)R[(long)m * p.ldr + n + e];
-          Y[(long)m * p.ldy + n + e] = (YT)s;
-        }
-      }
-    }
-  }
-}
-
-// ---- paired output columns -------------------------------------------------------------------------------------------
-// The weight tile is the MFMA A operand, so WHICH output column sits on MFMA row r of tile i is decided by the order of the
-// weight rows in LDS.  With the natural order a lane owns columns 16 i + 4 fq .. +3 of every tile: 8-byte accesses, 16
-// different cache lines per wave-instruction - and the loads of the residual / the stores of the result, not the MFMAs,
-// were what a short-K block spent its time on (in-kernel stamps: 2-5 us of a 13-16 us block).  Storing the rows of each
-// PAIR of tiles (2u, 2u+1) as  row(t, rho) <- column 32 u + 8 (rho >> 2) + 4 t + (rho & 3)  makes the lane's two 4-column
-// groups adjacent (columns 32 u + 8 fq .. +7): one 16-byte access where there were two 8-byte ones.  The permutation is
-// applied once, to the per-lane source row of the LDS-DMA; the fragment reads and the MFMAs are unchanged.
-template <int WNT>
-__device__ __forceinline__ int unpair_col(int pos) {  // LDS row position within the weight tile -> output column within the tile
-  const int w = pos / (16 * WNT);                       // which wave column (wn) the row belongs to
-  const int l = pos - w * (16 * WNT);                   // position inside that wave's 16*WNT rows
-  if (l >= 32 * (WNT / 2)) return pos;                  // unpaired last tile (odd WNT)
-  const int g = l >> 5, t = (l >> 4) & 1, rho = l & 15;
-  return w * (16 * WNT) + 32 * g + 8 * (rho >> 2) + 4 * t + (rho & 3);
-}
-
-// r2[u][j] / r1[j] / bpre[i]: residual (16 bytes per tile pair, 8 for an odd last tile) and bias of this lane in the paired
-// mapping, fetched ahead of the K loop (has_res / has_bias say whether they were).
-template <int WNT, int WMT>
-__device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)[WNT][WMT], int m0, int n0, int wm, int wn, int frow,
-                                                    int fq, int bz, const bf16x8 (&r2)[WNT / 2 > 0 ? WNT / 2 : 1][WMT],
-                                                    const bf16x4 (&r1)[WMT], bool has_res, const f32x4 (&bpre)[WNT], bool has_bias) {
-  bf16* Y = reinterpret_cast<bf16*>(p.y) + (long)bz * p.y_bs;
-  const int nb = n0 + wn * (16 * WNT);
-#pragma unroll
-  for (int j = 0; j < WMT; ++j) {
-    const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
-    if (m >= p.M) continue;
-    const float brow = (p.bias_mode == CRG_BIAS_ROW) ? p.bias[m] : 0.f;
-    const float* cv = p.cvec ? p.cvec + (long)(m / p.cvec_rows) * p.cvec_ld : nullptr;
-    auto finish = [&](f32x4 v, int i, int n) {
-      if (has_bias) v += bpre[i];
-      else if (p.bias_mode == CRG_BIAS_ROW) v += brow;
-      if (p.epi == CRG_EPI_SILU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = crg_silu_f(v[e]);
-      }
-      if (cv) v += *reinterpret_cast<const f32x4*>(cv + n);
-      return v;
-    };
-#pragma unroll
-    for (int u = 0; u < WNT / 2; ++u) {
-      const int n = nb + 32 * u + 8 * fq;
-      if (n >= p.N) continue;  // N % 8 == 0 in this mode: a group is in or out as a whole
-      f32x4 a = finish(acc[2 * u][j], 2 * u, n), b = finish(acc[2 * u + 1][j], 2 * u + 1, n + 4);
-      if (has_res) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          a[e] += (float)r2[u][j][e];
-          b[e] += (float)r2[u][j][4 + e];
-        }
-      }
-      bf16x8 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e] = (bf16)a[e];
-        o[4 + e] = (bf16)b[e];
-      }
-      *reinterpret_cast<bf16x8*>(Y + (long)m * p.ldy + n) = o;
-    }
-    if constexpr (WNT & 1) {
-      const int n = nb + 16 * (WNT - 1) + 4 * fq;
-      if (n < p.N) {
-        f32x4 a = finish(acc[WNT - 1][j], WNT - 1, n);
-        if (has_res) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) a[e] += (float)r1[j][e];
-        }
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16)a[e];
-        *reinterpret_cast<bf16x4*>(Y + (long)m * p.ldy + n) = o;
-      }
-    }
-  }
-}
 
 // KG = 2 (the split-bf16 path): 8 waves; the second group of four multiplies the second 32-wide k-step of every k-tile and
 // every thread stages half as many rows.  That path fills the LDS with one block per CU, and with one wave per SIMD the
@@ -529,11 +278,6 @@ __global__ __launch_bounds__(256 * KG) void gemm_kernel(GemmP p) {
 // done reading the buffer of tile t-1, which is the one the next DMA batch overwrites.  STAGES = 2 keeps two blocks per
 // CU (2 x 74 KB); grids that cannot put two blocks on a CU anyway run STAGES = 4 (147 KB) so that a lone block still
 // covers the ~1.5 us global -> LDS latency.
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {  // s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields left at "no wait")
-  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
-  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
-}
 
 template <int WNT, typename YT, bool CONV, int STAGES, int WMT, int KG, int NS = 1, bool PAIR = false>
 __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
@@ -1295,6 +1039,11 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
                              : (CONV ? (WNT == 5 ? CRG_K_CONV_W5 : WNT == 4 ? CRG_K_CONV_W4 : CRG_K_CONV_W1)
                                      : (WNT == 5 ? CRG_K_GEMM_W5 : WNT == 4 ? CRG_K_GEMM_W4 : CRG_K_GEMM_W1));
   crg_prof_scope ps(ctx, st, slot, wk.flops, wk.bytes);
+  if constexpr (GLDS && CONV && STAGES == 2 && WMT == 4 && KG == 1 && sizeof(YT) == 2 && (WNT == 4 || WNT == 5)) {
+    static const int ring = getenv("CRG_RING") ? atoi(getenv("CRG_RING")) : 1;  // dev knob: 0 = 2-stage 256-row kernel, 2 = spread DMA issue
+    if (halo && p.rowhalo == 2 && ring && p.a_bytes && p.w_bytes && (p.C2 == 0 || p.x2_bytes) && (long)p.M / (p.Ho * p.Wo) * p.H * p.W < (1 << 24))
+      return launch_conv_ring(ctx, st, p, WNT, ring - 1);
+  }
   hipLaunchKernelGGL(kern, grid, dim3(threads), lds_bytes, st, p);
   CRG_CHECK_LAUNCH(ctx, "gemm");
   return 0;
@@ -1559,6 +1308,13 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
                ((a->y_dtype == CRG_BF16 && a->prec == CRG_PREC_BF16) || (a->y_dtype == CRG_F32 && a->prec == CRG_PREC_BF16X3 && a->x_lo)))
                   ? 1 : 0;
   p.halo_lin = (a->Wo >= 16 && (a->Wo <= 128 ? 128 % a->Wo == 0 : a->Wo % 128 == 0)) ? 0 : 1;  // geometry of the output grid
+  {
+    const double ab = (double)a->N * a->H * a->W * a->C1 * 2.0, xb = (double)a->N * a->H * a->W * a->C2 * 2.0, wb = (double)p.N * p.K * 2.0;
+    const double lim = 2147483648.0;
+    p.a_bytes = ab < lim ? (unsigned)ab : 0;
+    p.x2_bytes = xb < lim ? (unsigned)xb : 0;
+    p.w_bytes = wb < lim ? (unsigned)wb : 0;
+  }
   const double flops = 2.0 * p.M * (double)p.N * p.K;
   const double bytes = (double)a->N * a->H * a->W * Ctot * crg_dtype_size(a->x_dtype) + (double)p.N * p.K * 2 +
                        (double)p.M * p.N * crg_dtype_size(a->y_dtype) * (a->residual ? 2 : 1);

@@ -241,6 +241,34 @@ def test_conv_rowhalo_shapes(N, C1, C2, H, W, Co):
         check(got, ref, BF, f"rowhalo conv {N}x{C1}+{C2}x{H}x{W}->{Co} {sorted(kw)}")
 
 
+@pytest.mark.parametrize("N,C1,C2,H,W,Co,up", [
+    (8, 320, 0, 64, 64, 320, False),    # 256 tiles of 256 x 160: one round, no split-K (SD1.5 64x64 level)
+    (8, 320, 320, 64, 64, 320, False),  # ... with the skip concat (second pointer switches at a chunk boundary)
+    (8, 640, 0, 32, 32, 640, False),    # 128 tiles x 2 K slices
+    (8, 1280, 0, 16, 16, 1280, False),  # 64 tiles x 4 K slices, 16 whole image rows per tile
+    (8, 1280, 0, 8, 8, 1280, False),    # linear-pixel row buffer (8x8 level), 16 K slices
+    (8, 640, 0, 32, 32, 640, True),     # nearest-2x upsample folded into the gather, 64x64 output
+    (8, 192, 64, 64, 64, 128, False),   # 128-wide tiles (WNT = 4), concat
+    (2, 128, 0, 128, 128, 320, False),  # W = 128 divides the tile: two image rows per tile
+    (1, 128, 0, 64, 512, 320, False),   # W = 512 > tile: one 256-pixel row SEGMENT per tile
+])
+def test_conv_ring_shapes(N, C1, C2, H, W, Co, up):
+    """3x3 convs whose grid fills rounds of 256-pixel tiles run on conv3_ring_kernel (conv_ring.hip: 4-slot weight ring,
+    counted vmcnt, cross-k-tile fragment prefetch): every buffer geometry, split-K, concat, upsample and epilogue term."""
+    from cremage_amd import ops
+    C = C1 + C2
+    x = rnd(N, C1, H, W, seed=180)
+    x2 = rnd(N, C2, H, W, seed=181) if C2 else None
+    w, b = rnd(Co, C, 3, 3, seed=182, scale=(9 * C) ** -0.5), rnd(Co, seed=183)
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    res, cvec = rnd(N, Co, Ho, Wo, seed=184), rnd(N, Co, seed=185)
+    for kw in (dict(), dict(cvec=cvec, res=res)):
+        ref = conv_ref(x, w, b, BF, x2=x2, up=up, **kw)
+        got = ops.conv2d(nhwc(x, BF), w.to(_dev()), b.to(_dev()), x2=nhwc(x2, BF) if C2 else None, upsample2x=up,
+                         cvec=kw["cvec"].to(_dev()) if "cvec" in kw else None, residual=nhwc(kw["res"], BF) if "res" in kw else None)
+        check(got, ref, BF, f"ring conv {N}x{C1}+{C2}x{H}x{W}->{Co} up={up} {sorted(kw)}")
+
+
 @pytest.mark.parametrize("N,C,H,W,Co", [(2, 64, 8, 8, 64), (1, 128, 16, 32, 160), (1, 64, 3, 64, 64), (1, 64, 2, 128, 64), (2, 64, 5, 12, 96)])
 def test_conv_rowhalo_upsample(N, C, H, W, Co):
     """nearest-2x upsample folded into the row-halo conv's gather (output-grid geometry, sources at (h >> 1, w >> 1)):
