@@ -169,6 +169,36 @@ __global__ __launch_bounds__(512, 2) void conv3_ring_kernel(GemmP p) {
     }
   };
 
+  // piece-granular forms of the two stagers (SPREAD == 3 threads single pieces through the MFMA groups)
+  struct XGroup { const void* base; unsigned bytes; int Cs2, soff, drow; unsigned bit; char* xb; bool mid; };
+  auto x_group = [&](int g) {
+    const int c = g / 3, kh = g - 3 * c;
+    const int cch = c * 64;
+    const bool second = cch >= p.C1;
+    XGroup r;
+    r.base = second ? p.x2 : p.a;
+    r.bytes = second ? p.x2_bytes : p.a_bytes;
+    r.Cs2 = 2 * (second ? p.C2 : p.C1);
+    r.soff = 2 * (second ? cch - p.C1 : cch);
+    r.drow = sh ? (kh == 2 ? p.W : 0) : kh * p.W;
+    r.bit = 1u << kh;
+    r.xb = xbuf + ((g - g_begin) & 1) * xbuf_bytes;
+    r.mid = sh && kh == 1;
+    return r;
+  };
+  auto x_piece = [&](int i, const XGroup& r) {
+    const int jp = wave + NW * i;
+    if (jp < XP) {  // wave-uniform
+      int px = xp0[i] + r.drow;
+      if (r.mid) px += (xmask[i] & 8u) ? p.W : 0;
+      const int vo = (xmask[i] & r.bit) ? px * r.Cs2 + clog * 16 : OOB;
+      dma16(r.base, r.bytes, r.xb + jp * 1024, vo, r.soff);
+    }
+  };
+  auto w_piece = [&](int q, int kt, int slot) {
+    if ((wave + NW * q) < WRG) dma16(p.w, p.w_bytes, wring + slot * WS_BYTES + (wave + NW * q) * 1024, wvo[q], kt * 128);
+  };
+
   f32x4 acc[WNT][WMT];
 #pragma unroll
   for (int i = 0; i < WNT; ++i)
@@ -241,6 +271,16 @@ __global__ __launch_bounds__(512, 2) void conv3_ring_kernel(GemmP p) {
 #endif
   };
 
+  auto mma_i = [&](const bf16x8 (&xf)[WMT], const bf16x8 (&wf)[WNT], int i) {  // the four MFMAs of weight fragment i
+#ifdef CRG_ABL_NOMMA
+    asm volatile("" ::"v"(wf[i]));
+#pragma unroll
+    for (int j = 0; j < WMT; ++j) asm volatile("" ::"v"(xf[j]));
+#else
+#pragma unroll
+    for (int j = 0; j < WMT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+#endif
+  };
   bf16x8 xf0[WMT], wf0[WNT], xf1[WMT], wf1[WNT];
   if (NT > 0) {
     // prologue: X(g0), W(0), W(1), W(2); first wait leaves W(1), W(2) in flight
@@ -263,8 +303,9 @@ __global__ __launch_bounds__(512, 2) void conv3_ring_kernel(GemmP p) {
   bf16x8 r2[PAIR ? (WNT / 2 > 0 ? WNT / 2 : 1) : 1][PAIR ? WMT : 1];
   bf16x4 r1[PAIR ? WMT : 1];
   f32x4 bpre[WNT];
-  const bool pre_res = p.res && p.splits == 1 && (p.ldr & 3) == 0 && (p.N & 3) == 0;
-  const bool pre_bias = p.bias_mode == CRG_BIAS_COL && p.splits == 1 && (p.N & 3) == 0;
+  const bool whole = p.splits == 1 || p.inred;  // this launch writes the finished output (no reduce kernel behind it)
+  const bool pre_res = p.res && whole && (p.ldr & 3) == 0 && (p.N & 3) == 0;
+  const bool pre_bias = p.bias_mode == CRG_BIAS_COL && whole && (p.N & 3) == 0;
   auto fetch_res = [&]() {
     const int nb = n0 + wn * (16 * WNT);
     if (pre_res) {
@@ -344,6 +385,54 @@ __global__ __launch_bounds__(512, 2) void conv3_ring_kernel(GemmP p) {
       }
 #endif
     };
+    if constexpr (SPREAD == 3) {
+      // Fine interleave: every group of four MFMAs is followed by ONE other item - a fragment-read burst or one or two DMA
+      // pieces - so that no wave ever sits in a long non-MFMA phase (in lockstep the two waves of a SIMD sat in theirs together
+      // and the matrix pipe idled: ablation, 0.35 us of LDS / barrier work + 0.19 us of DMA issue per k-tile on top of the MFMAs).
+#define SB __builtin_amdgcn_sched_barrier(0)
+#ifndef CRG_ABL_NODMA
+      const bool do_x = !FINAL && kw == 0 && next_g;
+      const bool do_w = !FINAL && tt + 3 < NT;
+#else
+      const bool do_x = false, do_w = false;
+#endif
+      XGroup xg{};
+      if (do_x) xg = x_group(g + 1);
+      const int wkt = 3 * g_begin + tt + 3, wslot = (tt + 3) & 3;
+      auto gap = [&](auto Kc) {  // DMA slot k: weight piece k (k < WL), then row-buffer piece k - WL
+        constexpr int k = decltype(Kc)::value;
+        if constexpr (k < WL) { if (do_w) w_piece(k, wkt, wslot); }
+        else if constexpr (k - WL < XI) { if (do_x) x_piece(k - WL, xg); }
+      };
+      using std::integral_constant;
+      mma_i(xf0, wf0, 0); SB;
+      read_x(xf1, xs, kw, 1); SB;
+      mma_i(xf0, wf0, 1); SB;
+      read_w(wf1, ws, 1); SB;
+      mma_i(xf0, wf0, 2); SB;
+      gap(integral_constant<int, 0>{}); gap(integral_constant<int, 1>{}); SB;
+      mma_i(xf0, wf0, 3); SB;
+      gap(integral_constant<int, 2>{}); gap(integral_constant<int, 3>{}); SB;
+      if constexpr (WNT > 4) { mma_i(xf0, wf0, 4); SB; }
+      if constexpr (!FINAL) {
+        const char* xs2 = (kw == 2) ? xbuf + ((g + 1 - g_begin) & 1) * xbuf_bytes : xs;
+        set_xoff(kw == 2 ? 0 : kw + 1);
+        read_x(xf0, xs2, kw == 2 ? 0 : kw + 1, 0);
+      } else {
+        fetch_res();
+      }
+      SB;
+      mma_i(xf1, wf1, 0); SB;
+      if constexpr (!FINAL) { read_w(wf0, wring + ((tt + 1) & 3) * WS_BYTES, 0); SB; }
+      mma_i(xf1, wf1, 1); SB;
+      gap(integral_constant<int, 4>{}); gap(integral_constant<int, 5>{}); SB;
+      mma_i(xf1, wf1, 2); SB;
+      gap(integral_constant<int, 6>{}); gap(integral_constant<int, 7>{}); SB;
+      mma_i(xf1, wf1, 3); SB;
+      if constexpr (WNT > 4) mma_i(xf1, wf1, 4);
+#undef SB
+      return;
+    }
     const bool early = SPREAD == 0 || (SPREAD == 2 && wave < 4);
     if (early) issue();
     read_x(xf1, xs, kw, 1);
@@ -382,6 +471,59 @@ __global__ __launch_bounds__(512, 2) void conv3_ring_kernel(GemmP p) {
       fetch_res();
     }
   }
+  if (p.splits > 1 && p.inred) {
+    // ---- in-launch split-K sum (guide 5, "In-launch split-K reduction"; placement-independent, no spin, no float atomics) ----
+    // every slice stores its accumulators as a register image (f32x4 per lane, 1 KiB coalesced wave-stores), drains, and ONE lane
+    // releases (agent scope) and takes a ticket; the block that draws the last ticket acquires, sums the slices IN SLICE ORDER
+    // (its own from registers) - bitwise the same whichever block comes last - and writes the output.
+    const long tile_lin = (long)tile_m * p.tiles_n + tile_n;
+    constexpr int IMG = WNT * WMT * 64;  // f32x4 per wave image
+    f32x4* const slab4 = reinterpret_cast<f32x4*>(p.slab);
+    f32x4* img = slab4 + ((tile_lin * p.splits + sid) * NW + wave) * IMG + lane;
+#pragma unroll
+    for (int i = 0; i < WNT; ++i)
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) img[(i * WMT + j) * 64] = acc[i][j];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // all slab stores of the block issued and acknowledged; the LDS is idle from here on
+    unsigned* const flag = reinterpret_cast<unsigned*>(smem);
+    if (t == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // keep: the compiler may drop the fence's own wait (guide G16 pitfall 12)
+      *flag = __hip_atomic_fetch_add(p.tile_cnt + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned ticket = *flag;
+    if (ticket != (unsigned)(p.splits - 1)) return;
+    if (t == 0) {
+      __hip_atomic_store(p.tile_cnt + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // sum = ((p0 + p1) + p2) + ... over ALL slices' images in slice order, this block's own re-read like the others (it is the
+    // same fp32 values; keeping it in registers beside a running sum and a slice in flight needs 240 VGPRs and spilled).
+    // Each slice is requested whole - 20 independent 16-byte loads in flight - before it is added.
+    f32x4 tmp[WNT][WMT];
+    for (int s2 = 0; s2 < p.splits; ++s2) {
+      const f32x4* src = slab4 + ((tile_lin * p.splits + s2) * NW + wave) * IMG + lane;
+#pragma unroll
+      for (int i = 0; i < WNT; ++i)
+#pragma unroll
+        for (int j = 0; j < WMT; ++j) tmp[i][j] = src[(i * WMT + j) * 64];
+      if (s2 == 0) {
+#pragma unroll
+        for (int i = 0; i < WNT; ++i)
+#pragma unroll
+          for (int j = 0; j < WMT; ++j) acc[i][j] = tmp[i][j];
+      } else {
+#pragma unroll
+        for (int i = 0; i < WNT; ++i)
+#pragma unroll
+          for (int j = 0; j < WMT; ++j) acc[i][j] += tmp[i][j];
+      }
+    }
+  }
   if constexpr (PAIR) {
     gemm_epilogue_pairs<WNT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, 0, r2, r1, pre_res, bpre, pre_bias);
   } else {
@@ -395,16 +537,16 @@ int launch_conv_ring(crg_ctx* ctx, hipStream_t st, const GemmP& p, int wnt, int 
   const bool lin = p.halo_lin != 0;
 #define CRG_RING_PICK(W, S) (p.pair ? (lin ? conv3_ring_kernel<W, true, S, true> : conv3_ring_kernel<W, true, S, false>) \
                                     : (lin ? conv3_ring_kernel<W, false, S, true> : conv3_ring_kernel<W, false, S, false>))
-  if (wnt == 5) kern = spread == 2 ? CRG_RING_PICK(5, 2) : spread ? CRG_RING_PICK(5, 1) : CRG_RING_PICK(5, 0);
-  else if (wnt == 4) kern = spread == 2 ? CRG_RING_PICK(4, 2) : spread ? CRG_RING_PICK(4, 1) : CRG_RING_PICK(4, 0);
+  if (wnt == 5) kern = spread == 3 ? CRG_RING_PICK(5, 3) : spread == 2 ? CRG_RING_PICK(5, 2) : spread ? CRG_RING_PICK(5, 1) : CRG_RING_PICK(5, 0);
+  else if (wnt == 4) kern = spread == 3 ? CRG_RING_PICK(4, 3) : spread == 2 ? CRG_RING_PICK(4, 2) : spread ? CRG_RING_PICK(4, 1) : CRG_RING_PICK(4, 0);
   else return crg_fail(ctx, -22, "conv ring: unsupported tile width %d", wnt);
 #undef CRG_RING_PICK
   const int BN = 32 * wnt, TP = 256;
   const int XP = (p.halo_lin || p.Wo > TP) ? (TP + 2 + 7) / 8 : ((TP / p.Wo) * (p.Wo + 2) + 7) / 8;
   if (XP > 40) return crg_fail(ctx, -22, "conv ring: row buffer of %d pieces unsupported", XP);
   const size_t lds = (size_t)4 * BN * 128 + (size_t)2 * XP * 1024;
-  static bool attr_set[24] = {};
-  const int ai = (wnt == 5 ? 12 : 0) + spread * 4 + (p.pair ? 2 : 0) + (lin ? 1 : 0);
+  static bool attr_set[32] = {};
+  const int ai = (wnt == 5 ? 16 : 0) + spread * 4 + (p.pair ? 2 : 0) + (lin ? 1 : 0);
   if (!attr_set[ai]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return crg_fail(ctx, -5, "conv ring: cannot set dynamic LDS: %s", hipGetErrorString(e));

@@ -54,10 +54,11 @@ extern "C" int crg_ctx_create(int device, crg_ctx** out) {
   crg_ctx* c = new (std::nothrow) crg_ctx();
   if (!c) return -12;
   c->device = device;
-  if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
+  if (hipMalloc(&c->zero_page, 4096 + 16384) != hipSuccess || hipMemset(c->zero_page, 0, 4096 + 16384) != hipSuccess) {
     delete c;
     return -12;
   }
+  c->tile_cnt = reinterpret_cast<unsigned*>(static_cast<char*>(c->zero_page) + 4096);
   *out = c;
   return 0;
 }

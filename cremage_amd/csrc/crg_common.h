@@ -34,6 +34,7 @@ struct crg_ctx {
   size_t scratch_bytes = 0;
   std::vector<void*> retired;  // outgrown scratch buffers (kept alive: captured graphs / queued kernels may reference them)
   void* zero_page = nullptr;  // 4 KiB of zeros: LDS-DMA source for conv padding and tile tails
+  unsigned* tile_cnt = nullptr;  // 4096 split-K arrival counters (zero between launches: the last arriver resets its tile's), behind the zero page
   bool profiling = false;
   std::vector<crg_prof_rec> recs;
   std::vector<hipEvent_t> event_pool;

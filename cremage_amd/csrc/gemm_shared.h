@@ -28,6 +28,9 @@ struct GemmP {
   int rowhalo;     // conv: eligible for conv3_rowhalo_kernel (3x3, stride 1, pad 1, chunk-major K); 2 = on 256-row tiles
   int halo_lin;    // ... with the linear-pixel row buffer (widths that neither divide the tile nor are a multiple of it)
   int ks_q, ks_r;  // k-tiles per K-slice: nk_total = splits * ks_q + ks_r
+  int ring;             // conv: runs on conv3_ring_kernel (conv_ring.hip)
+  int inred;            // ... which sums its K slices itself: slab = register images [tile][slice][wave][i][j][lane] f32x4,
+  unsigned* tile_cnt;   //     arrival counter per tile (zero on entry, reset by the last arriver)
   unsigned a_bytes, x2_bytes, w_bytes;  // conv: byte sizes of x, x2 and the packed weight (buffer descriptors of conv_ring.hip); 0 = unknown / >= 2 GiB
   int xg_m, xg_n, xg_s;  // XCD partition of the (m-tile, n-tile, k-slice) grid, product 8; xg_s == 0: legacy contiguous order
 };
@@ -71,7 +74,7 @@ template <int WNT, typename YT, int WMT = 4>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][WMT], int m0, int n0, int wm, int wn, int frow, int fq,
                                               int bz, int sid, const bf16x4 (&pre)[WNT][WMT], bool use_pre,
                                               const f32x4 (&bpre)[WNT], bool use_bpre) {
-  if (p.splits > 1) {
+  if (p.splits > 1 && !p.inred) {
     const long srows = p.M - p.slab_row0;
     float* S = p.slab + ((long)bz * p.splits + sid) * srows * p.N - (long)p.slab_row0 * p.N;
 #pragma unroll
