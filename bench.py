@@ -39,11 +39,12 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (C2: 4)")
     ap.add_argument("--sampler_steps", type=int, default=20)
     ap.add_argument("--sampler", default="euler_a")
-    ap.add_argument("--workload", default="sd15", choices=["sd15", "sdxl", "img2img", "controlnet"],
+    ap.add_argument("--workload", default="sd15", choices=["sd15", "sdxl", "img2img", "controlnet", "c5"],
                     help="sd15 = BASELINE.json configs[1] (the headline metric, default).  Extra, separately labelled measurements: "
                          "sdxl = configs[2] (SDXL 1024x1024 batch 2, 30-step Euler EDM); img2img = configs[3]'s per-GPU unit (SD1.5 "
                          "img2img 768x768, 2 images per GPU, DDIM 20 steps strength 0.75, VAE encode + decode); controlnet = "
-                         "configs[1] with a ControlNet attached (SURVEY 8f row 1)")
+                         "configs[1] with a ControlNet attached (SURVEY 8f row 1); c5 = configs[4]'s per-GPU unit (SDXL 1024x1024 txt2img, 1 image per GPU, then the "
+                         "auto-face-fix second pass: img2img strength 0.3 on a crop brought to 1024x1024 = UNet re-entry + VAE encode + decode)")
     ap.add_argument("--no-graph", action="store_true", help="launch the UNet eagerly instead of replaying a captured hipGraph "
                                                             "(measured A/B on MI355X: replay is 0-3 % faster and steadier)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -54,7 +55,7 @@ def main():
     from cremage_amd import ops, pipeline as P
     from cremage_amd.synth import synth_input
 
-    if a.workload == "sdxl":
+    if a.workload in ("sdxl", "c5"):
         return main_sdxl(a)
     if a.workload in ("img2img", "controlnet"):
         return main_extra(a)
@@ -114,6 +115,11 @@ def main():
     n_images = world * b * a.steps
     value = n_images / dt
     flops_per_image = a.sampler_steps * 2 * FLOPS_UNET_PER_SAMPLE + FLOPS_VAE_DECODE
+    gm = ldm.model.graphed  # None with --no-graph
+    unet_calls = a.sampler_steps * (a.warmup + a.steps)
+    graph_replay = bool(gm is not None and gm.active and gm.replays >= unet_calls - 2 * gm.captures)
+    if gm is not None and not graph_replay:  # strict capture raises; this catches a silent eager run all the same
+        raise SystemExit(f"hipGraph replay was requested but only {gm.replays} of {unet_calls} UNet calls were replays")
     res = {
         "metric": "images/sec SD1.5 512x512 20-step Euler ancestral (txt2img, CFG 7.5, incl. VAE decode)",
         "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -125,6 +131,10 @@ def main():
                    "parallelism": f"batch-sharded x{world} (weights broadcast {bcast_bytes / 1e9:.2f} GB once, images all-gathered per step)"},
         "whole_path_mfma_frac": round(value / world * flops_per_image / (PEAK_BF16_TFLOPS * 1e12), 4),
         "model_build_s": round(t_build, 1),
+        # how the TIMED steps launched the UNet: true = every UNet call was one hipGraph replay (captured once per
+        # conditioning; the VAE decode and the sampler arithmetic are eager launches either way)
+        "graph_replay": graph_replay,
+        "graph_captures": gm.captures if gm is not None else 0,
     }
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, one extra un-timed step ----
@@ -135,6 +145,7 @@ def main():
             step()
         fam = prof.result
         res["roofline"] = roofline_of(prof.kernels)
+        res["roofline"]["timed_eager"] = True  # this extra step is launched eagerly with an event pair around every kernel
         res["kernel_families_ms_per_step"] = {k: round(v["ms"], 3) for k, v in fam.items() if v["launches"]}
         res["kernel_families_tflops_or_gbs"] = {
             k: (round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if k in ("gemm", "conv", "attention") else round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1))
@@ -195,7 +206,12 @@ def roofline_of(kernels):
             "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": src, "launches": k["launches"],
             "avg_launch_us": round(1e3 * k["ms"] / n, 2), "algorithmic_gflop_per_launch": round(k["flops"] / n / 1e9, 3),
             "algorithmic_mbytes_per_launch": round(k["bytes"] / n / 1e6, 3),
-            "kernels_ms_per_step": {name: round(v["ms"], 3) for name, v in kernels.items() if v["launches"]}}
+            "kernels_ms_per_step": {name: round(v["ms"], 3) for name, v in kernels.items() if v["launches"]},
+            # per slot: launches and ALGORITHMIC work per launch (FLOPs = 2 MAC of the op; bytes = operands + result once)
+            "kernels_per_launch": {name: {"launches": v["launches"], "us": round(1e3 * v["ms"] / v["launches"], 2),
+                                          "gflop": round(v["flops"] / v["launches"] / 1e9, 3),
+                                          "mbytes": round(v["bytes"] / v["launches"] / 1e6, 3)}
+                                   for name, v in kernels.items() if v["launches"]}}
 
 
 def main_extra(a):
@@ -286,7 +302,8 @@ def main_sdxl(a):
     rank, world, local = D.init_from_env()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    b = 2 if a.batch == 4 else a.batch
+    c5 = a.workload == "c5"
+    b = (1 if c5 else 2) if a.batch == 4 else a.batch
     steps = 30 if a.sampler_steps == 20 else a.sampler_steps
     t0 = time.time()
     eng = P.build_synthetic_sdxl(device=dev, fill=(rank == 0))
@@ -301,7 +318,12 @@ def main_sdxl(a):
 
     def step():
         x0 = torch.stack([torch.randn((4, 128, 128), generator=g, device=dev) for g in gens])
-        images, _ = P.txt2img_sdxl(eng, c, uc, steps=steps, cfg_scale=5.0, x0=x0)
+        if c5:  # first pass, then the face-fix re-entry on a fixed 512x512 box brought to 1024x1024 (one "face" per image)
+            rn = lambda: torch.stack([torch.randn((4, 128, 128), generator=g, device=dev) for g in gens])
+            images, _, _ = P.txt2img_sdxl_facefix(eng, c, uc, [(256, 256, 512)] * b, steps=steps, cfg_scale=5.0, x0=x0, strength=0.3,
+                                                  enc_noise=rn(), fwd_noise=rn())
+        else:
+            images, _ = P.txt2img_sdxl(eng, c, uc, steps=steps, cfg_scale=5.0, x0=x0)
         return D.all_gather_batch(images)
 
     for _ in range(a.warmup):
@@ -317,12 +339,21 @@ def main_sdxl(a):
     assert out.shape == (world * b, 3, 1024, 1024) and torch.isfinite(out).all()
     value = world * b * a.steps / dt
     flops_per_image = steps * 2 * 6760e9 + 10470.4e9
-    res = {"metric": "images/sec SDXL 1024x1024 base-only 30-step Euler EDM (txt2img, CFG 5, incl. VAE decode)", "value": round(value, 4),
+    metric = "images/sec SDXL 1024x1024 base-only 30-step Euler EDM (txt2img, CFG 5, incl. VAE decode)"
+    workload = ("SDXL txt2img 1024x1024 base-only, batch 2 per GPU, 30-step Euler EDM, bf16 UNet (B=4 with CFG) + "
+                "fp32-class VAE decode, synthetic weights/conditioning (BASELINE.json configs[2])")
+    if c5:
+        n2 = max(int(0.3 * (steps + 1)), 1) - 1  # UNet steps of the second pass: the pruned schedule keeps int(0.3 * (steps + 1)) sigmas
+        # + VAE encode at 1024^2 (4 x the 512^2 figure of SURVEY 8d: conv-only encoder) + n2 x 2 UNet calls + a second decode
+        flops_per_image += 4 * 1116.7e9 + n2 * 2 * 6760e9 + 10470.4e9
+        metric = "images/sec SDXL 1024x1024 30-step Euler EDM + auto-face-fix second pass (img2img strength 0.3 on a crop, UNet re-entry)"
+        workload = (f"SDXL txt2img 1024x1024 + face-fix re-entry (BASELINE.json configs[4] per-GPU unit): {b} image per GPU, 30-step Euler EDM, "
+                    f"then a fixed 512x512 box resized to 1024x1024 -> VAE encode -> {n2} Euler-EDM steps (strength 0.3) x CFG -> VAE decode "
+                    "-> paste; bf16 UNet, fp32-class VAE; box instead of the face detector, bilinear instead of cv2 Lanczos (out of scope)")
+    res = {"metric": metric, "value": round(value, 4),
            "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": "SDXL txt2img 1024x1024 base-only, batch 2 per GPU, 30-step Euler EDM, bf16 UNet (B=4 with CFG) + "
-                                  "fp32-class VAE decode, synthetic weights/conditioning (BASELINE.json configs[2])",
-                      "images_per_gpu_per_step": b, "sampler_steps": steps},
+           "config": {"workload": workload, "images_per_gpu_per_step": b, "sampler_steps": steps},
            "whole_path_mfma_frac": round(value / world * flops_per_image / (PEAK_BF16_TFLOPS * 1e12), 4), "model_build_s": round(t_build, 1)}
     if rank == 0 and not a.no_roofline:
         with ops.profile(local) as prof:

@@ -84,6 +84,8 @@ SIGNATURES = {
     "crg_pack_geglu_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "crg_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                               c_int, c_int, c_int, c_int, c_int, c_float, c_int]),
+    "crg_attention_v": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                              c_int, c_int, c_int, c_int, c_int, c_float, c_int]),
     "crg_softmax_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_float, c_int]),
     "crg_conv_small": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int]),

@@ -11,8 +11,11 @@
 //        converted pairwise to bf16: guide §3 "An accumulator tile as the next MFMA's operand"; the
 //        k order inside a 16-key step is row 16s + 8(j>>2) + 4h + (j&3), so V^T is read as two 8-byte
 //        pieces per step at key offsets 16s+4h and 16s+8+4h).
-// V arrives TRANSPOSED from HBM ([channel][key]; emitted by the V projection GEMM with swapped
-// operands), so no transposing LDS read is needed.  Head dims are padded to KS*16 (QK^T) and NV*32
+// V arrives either TRANSPOSED from HBM ([channel][key]; emitted by a V projection GEMM with swapped operands: crg_attention)
+// or ROW-MAJOR ([key][channel], the third slice of ONE fused Q|K|V projection: crg_attention_v, VRM = true).  Row-major V is
+// staged as [32-channel block][64 keys][32 channels] (64-byte rows) and the V^T fragments come out of ds_read_b64_tr_b16
+// (guide T10: per 16-lane group a 4-row x 16-column block, delivered column-major): the transposed projection launch
+// disappears and the LDS image is conflict-free (four 64-byte rows of a block fill one 256-byte bank row).  Head dims are padded to KS*16 (QK^T) and NV*32
 // (PV) with zeros: d_head 40 -> 48/64, 80 -> 80/96, 160 -> 160/160, 64 -> 64/64.
 //
 // LDS: K tile [64][KS*16] with rows padded to 16*(2KS+1) bytes, V^T tile [NV*32][64] with rows padded
@@ -44,13 +47,13 @@ __device__ unsigned long long crg_attn_laps[32 * 8];
 
 constexpr int VROW = 136;  // bytes per V^T LDS row (64 keys * 2 B + 8 pad)
 
-template <int KS, int NV, bool ONES>
+template <int KS, int NV, bool ONES, bool VRM = false>
 __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_kernel(AttnP p) {
   constexpr int KROW = KS * 32 + 16;  // bytes per K LDS row
   constexpr int KCH = 2 * KS;         // 16-byte chunks per K row
   constexpr int KLOADS = (64 * KCH + 255) / 256;
   constexpr int KBYTES = 64 * KROW;
-  constexpr int VBYTES = NV * 32 * VROW;
+  constexpr int VBYTES = VRM ? NV * 4096 : NV * 32 * VROW;
   // two stages of {K tile, V^T tile}: tile t+1 is written while tile t is being read, one barrier per tile
   __shared__ __attribute__((aligned(16))) char smem[2 * (KBYTES + VBYTES)];
 
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
 
   const bf16* Q = p.q + (long)b * p.Nq * p.ldq + (long)h * p.Dh;
   const bf16* K = p.k + (long)b * p.Nk * p.ldk + (long)h * p.Dh;
-  const bf16* VT = p.vt + ((long)b * p.H + h) * p.Dh * p.ldvt;
+  const bf16* VT = VRM ? p.vt + (long)b * p.Nk * p.ldvt + (long)h * p.Dh : p.vt + ((long)b * p.H + h) * p.Dh * p.ldvt;
   bf16* O = p.o + (long)b * p.Nq * p.ldo + (long)h * p.Dh;
 
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -121,9 +124,27 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int idx = t + 256 * i;
-    const int row = idx >> 3, c = idx & 7;
-    vmode[i] = row < p.Dh ? 1 : ((ones_row && row == p.Dh) ? 2 : 0);
-    vptr[i] = VT + (long)row * p.ldvt + c * 8;
+    if constexpr (VRM) {  // chunk slot (key, c): 8 channels 8c .. 8c + 7 of one key; slots past Dh are constants (set once below)
+      const int key = idx / (4 * NV), c = idx - key * (4 * NV);
+      vmode[i] = c * 8 < p.Dh ? 1 : 0;
+      vptr[i] = VT + (long)key * p.ldvt + c * 8;
+    } else {
+      const int row = idx >> 3, c = idx & 7;
+      vmode[i] = row < p.Dh ? 1 : ((ones_row && row == p.Dh) ? 2 : 0);
+      vptr[i] = VT + (long)row * p.ldvt + c * 8;
+    }
+  }
+  if constexpr (VRM) {
+    // constant part of both V stages: zeros, and 1.0 in channel Dh of every key (the softmax-denominator column)
+    uint4* z = reinterpret_cast<uint4*>(smem);
+    for (int i = t; i < 2 * (KBYTES + VBYTES) / 16; i += 256) z[i] = uint4{0, 0, 0, 0};
+    __syncthreads();
+    if (ones_row && t < 128) {
+      const int st = t >> 6, key = t & 63;
+      const int blk = p.Dh >> 5, col = p.Dh & 31;
+      *reinterpret_cast<bf16*>(smem + st * (KBYTES + VBYTES) + KBYTES + blk * 4096 + key * 64 + col * 2) = one;
+    }
+    __syncthreads();
   }
   auto prefetch = [&](int tile) {
     const int kbase = tile * 64;
@@ -131,14 +152,24 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
 #pragma unroll
       for (int i = 0; i < KLOADS; ++i) kreg[i] = kuse[i] ? *reinterpret_cast<const bf16x8*>(kptr[i] + (long)kbase * p.ldk) : zero8;
 #pragma unroll
-      for (int i = 0; i < NV; ++i)
-        vreg[i] = vmode[i] == 1 ? *reinterpret_cast<const bf16x8*>(vptr[i] + kbase) : (vmode[i] == 2 ? ones8 : zero8);
+      for (int i = 0; i < NV; ++i) {
+        if constexpr (VRM) vreg[i] = vmode[i] == 1 ? *reinterpret_cast<const bf16x8*>(vptr[i] + (long)kbase * p.ldvt) : zero8;
+        else vreg[i] = vmode[i] == 1 ? *reinterpret_cast<const bf16x8*>(vptr[i] + kbase) : (vmode[i] == 2 ? ones8 : zero8);
+      }
       return;
     }
 #pragma unroll
     for (int i = 0; i < KLOADS; ++i) {
       const int row = (t + 256 * i) / KCH;
       kreg[i] = (kuse[i] && kbase + row < p.Nk) ? *reinterpret_cast<const bf16x8*>(kptr[i] + (long)kbase * p.ldk) : zero8;
+    }
+    if constexpr (VRM) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int key = (t + 256 * i) / (4 * NV);
+        vreg[i] = (vmode[i] == 1 && kbase + key < p.Nk) ? *reinterpret_cast<const bf16x8*>(vptr[i] + (long)kbase * p.ldvt) : zero8;
+      }
+      return;
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -165,6 +196,15 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
       const int idx = t + 256 * i;
       const int row = idx / KCH, c = idx - row * KCH;
       if (idx < 64 * KCH) *reinterpret_cast<bf16x8*>(Ks + row * KROW + c * 16) = kreg[i];
+    }
+    if constexpr (VRM) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int idx = t + 256 * i;
+        const int key = idx / (4 * NV), c = idx - key * (4 * NV);
+        if (vmode[i] == 1) *reinterpret_cast<bf16x8*>(Vs + (c >> 2) * 4096 + key * 64 + (c & 3) * 16) = vreg[i];  // constant slots stay
+      }
+      return;
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -257,14 +297,29 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
 #pragma unroll
     for (int dv = 0; dv < NV; ++dv) {
       const char* vrow = Vs + (dv * 32 + r) * VROW;
+      // VRM: transposed read.  16-lane group g = lane / 16 takes channels 16 (g & 1) .. + 15 of keys 4 (g >> 1) .. + 3 (plus the
+      // k-step's base key); lane 4 q + pp of the group supplies the address of key row q, channels 4 pp .. 4 pp + 3, and
+      // receives its own channel of the four keys - the k order 16 s + 8 (j >> 2) + 4 hh + (j & 3) the P fragment has.
+      typedef short s16x4 __attribute__((ext_vector_type(4)));
+      typedef __attribute__((address_space(3))) s16x4* trptr_t;
+      const char* vtr = Vs + dv * 4096 + (4 * (lane >> 5) + ((lane >> 2) & 3)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const int keyoff = kb * 32 + 16 * s2 + 4 * hh;
-          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + keyoff * 2);
-          const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + (keyoff + 8) * 2);
-          const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          bf16x8 vf;
+          if constexpr (VRM) {
+            const char* a0 = vtr + (kb * 32 + 16 * s2) * 64;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)a0);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)(a0 + 8 * 64));
+            const short v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            __builtin_memcpy(&vf, v8, 16);
+          } else {
+            const int keyoff = kb * 32 + 16 * s2 + 4 * hh;
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + keyoff * 2);
+            const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + (keyoff + 8) * 2);
+            vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
           oacc[dv] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], oacc[dv], 0, 0, 0);
         }
     }
@@ -314,27 +369,32 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
 }
 
 template <int KS, int NV>
-int launch_attn(crg_ctx* ctx, hipStream_t st, const AttnP& p) {
+int launch_attn(crg_ctx* ctx, hipStream_t st, const AttnP& p, bool vrm) {
   dim3 grid((p.Nq + 127) / 128, p.B * p.H);
-  if (p.Dh < NV * 32) hipLaunchKernelGGL((attn_kernel<KS, NV, true>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((attn_kernel<KS, NV, false>), grid, dim3(256), 0, st, p);
+  if (vrm) {
+    if (p.Dh < NV * 32) hipLaunchKernelGGL((attn_kernel<KS, NV, true, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_kernel<KS, NV, false, true>), grid, dim3(256), 0, st, p);
+  } else {
+    if (p.Dh < NV * 32) hipLaunchKernelGGL((attn_kernel<KS, NV, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_kernel<KS, NV, false>), grid, dim3(256), 0, st, p);
+  }
   CRG_CHECK_LAUNCH(ctx, "attention");
   return 0;
 }
 
 }  // namespace
 
-extern "C" int crg_attention(crg_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k, int64_t ldk,
-                             const void* vt, int64_t ldvt, void* o, int64_t ldo, int B, int H, int Nq, int Nk, int Dh,
-                             float scale, int dtype) {
+static int attention_entry(crg_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                           void* o, int64_t ldo, int B, int H, int Nq, int Nk, int Dh, float scale, int dtype, bool vrm) {
   if (!ctx) return -22;
   CRG_REQUIRE(ctx, dtype == CRG_BF16, "attention: only bf16 is implemented (dtype %d)", dtype);
   CRG_REQUIRE(ctx, B > 0 && H > 0 && Nq > 0 && Nk > 0, "attention: empty problem B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
   CRG_REQUIRE(ctx, Dh % 8 == 0 && Dh >= 8 && Dh <= 160, "attention: head dim %d unsupported (multiple of 8, <= 160)", Dh);
-  CRG_REQUIRE(ctx, ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attention: leading dimensions must keep 16-byte alignment");
-  CRG_REQUIRE(ctx, ldvt >= ((Nk + 7) / 8) * 8, "attention: ldvt=%ld must cover Nk=%d rounded up to 8", (long)ldvt, Nk);
-  CRG_REQUIRE(ctx, (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) == 0 && ((uintptr_t)o & 7) == 0, "attention: pointers must be 16-byte aligned");
-  AttnP p{(const bf16*)q, (const bf16*)k, (const bf16*)vt, (bf16*)o, (long)ldq, (long)ldk, (long)ldvt, (long)ldo, B, H, Nq, Nk, Dh,
+  CRG_REQUIRE(ctx, ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attention: leading dimensions must keep 16-byte alignment");
+  if (vrm) CRG_REQUIRE(ctx, ldv >= (int64_t)H * Dh, "attention: ldv=%ld must cover H*Dh=%d", (long)ldv, H * Dh);
+  else CRG_REQUIRE(ctx, ldv >= ((Nk + 7) / 8) * 8, "attention: ldvt=%ld must cover Nk=%d rounded up to 8", (long)ldv, Nk);
+  CRG_REQUIRE(ctx, (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)o & 7) == 0, "attention: pointers must be 16-byte aligned");
+  AttnP p{(const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, (long)ldq, (long)ldk, (long)ldv, (long)ldo, B, H, Nq, Nk, Dh,
           scale * 1.4426950408889634f};
   hipStream_t st = (hipStream_t)stream;
   const double flops = 4.0 * B * H * (double)Nq * Nk * Dh;
@@ -342,18 +402,30 @@ extern "C" int crg_attention(crg_ctx* ctx, void* stream, const void* q, int64_t 
   crg_prof_scope ps(ctx, st, CRG_K_ATTN, flops, bytes);
   const int ks = (Dh + 15) / 16;
   switch (ks) {
-    case 1: return launch_attn<1, 1>(ctx, st, p);
-    case 2: return launch_attn<2, 1>(ctx, st, p);
-    case 3: return launch_attn<3, 2>(ctx, st, p);
-    case 4: return launch_attn<4, 2>(ctx, st, p);
-    case 5: return launch_attn<5, 3>(ctx, st, p);
-    case 6: return launch_attn<6, 3>(ctx, st, p);
-    case 7: return launch_attn<7, 4>(ctx, st, p);
-    case 8: return launch_attn<8, 4>(ctx, st, p);
-    case 9: return launch_attn<9, 5>(ctx, st, p);
-    case 10: return launch_attn<10, 5>(ctx, st, p);
+    case 1: return launch_attn<1, 1>(ctx, st, p, vrm);
+    case 2: return launch_attn<2, 1>(ctx, st, p, vrm);
+    case 3: return launch_attn<3, 2>(ctx, st, p, vrm);
+    case 4: return launch_attn<4, 2>(ctx, st, p, vrm);
+    case 5: return launch_attn<5, 3>(ctx, st, p, vrm);
+    case 6: return launch_attn<6, 3>(ctx, st, p, vrm);
+    case 7: return launch_attn<7, 4>(ctx, st, p, vrm);
+    case 8: return launch_attn<8, 4>(ctx, st, p, vrm);
+    case 9: return launch_attn<9, 5>(ctx, st, p, vrm);
+    case 10: return launch_attn<10, 5>(ctx, st, p, vrm);
   }
   return crg_fail(ctx, -22, "attention: head dim %d unsupported", Dh);
+}
+
+extern "C" int crg_attention(crg_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                             const void* vt, int64_t ldvt, void* o, int64_t ldo, int B, int H, int Nq, int Nk, int Dh,
+                             float scale, int dtype) {
+  return attention_entry(ctx, stream, q, ldq, k, ldk, vt, ldvt, o, ldo, B, H, Nq, Nk, Dh, scale, dtype, false);
+}
+
+extern "C" int crg_attention_v(crg_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                               const void* v, int64_t ldv, void* o, int64_t ldo, int B, int H, int Nq, int Nk, int Dh,
+                               float scale, int dtype) {
+  return attention_entry(ctx, stream, q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, Dh, scale, dtype, true);
 }
 
 #ifdef CRG_ATTN_LAPS

@@ -12,7 +12,18 @@ Correctness rules enforced here:
     inside the modules and therefore NOT part of the captured work); a new prompt -> a new capture;
   * two eager warm-up calls run before capture so that every weight pack, cache fill, hipFuncSetAttribute and scratch
     growth happens outside the capture; the context scratch is additionally reserved up front;
-  * parameters must not be replaced while a graph is alive (`invalidate()` after load_state_dict / LoRA changes).
+  * a graph OWNS every step-invariant tensor it was captured against that lives outside its allocator pool: the
+    conditioning, the per-module cross-attention K / V^T caches and the cast copy of the context (all written by the
+    eager warm-up).  They are snapshotted into the graph record after warm-up, so a later capture for another prompt,
+    which overwrites the modules' single-slot caches, cannot free memory an older graph still reads
+    (ctx A -> ctx B -> ctx A replays graph A against its own, still-live K/V);
+  * a graph is keyed on a WEIGHT STAMP as well: the (data_ptr, _version) of every parameter of the module (about 0.1 ms of
+    host time per call, overlapped with the previous replay) and an epoch that is bumped whenever a Parameter is registered
+    on any module (LoRA `setattr`, image_generator.py:408-453) or a packed weight image is rebuilt.  load_state_dict
+    (in-place copy -> version), `.to()` / `.half()` (new storage -> data_ptr) and LoRA swaps therefore re-capture instead of
+    replaying against stale or freed weight images; `invalidate()` remains for writes through `.data`, which no counter sees;
+  * a failed capture RAISES (`strict=True`, the default): the caller asked for replay, and a silent switch to eager
+    launches would make a timing unattributable.  `strict=False` restores the warn-and-go-eager behaviour.
 """
 from __future__ import annotations
 
@@ -22,17 +33,51 @@ from typing import Dict, Tuple
 import torch
 
 from . import _lib as L
+from .ops import TensorKeyedCache
+
+
+def _on_parameter_registered(module, name, param):
+    TensorKeyedCache.epoch += 1
+    return None
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_on_parameter_registered)
 
 
 class GraphedModule:
     def __init__(self, module: torch.nn.Module, const_args: Tuple[str, ...] = ("context",), scratch_bytes: int = 1 << 30,
-                 max_graphs: int = 4):
+                 max_graphs: int = 4, strict: bool = True):
         self.module = module
         self.const_args = const_args
         self.scratch_bytes = scratch_bytes
         self.max_graphs = max_graphs
+        self.strict = strict
         self._graphs: Dict[tuple, tuple] = {}
         self.broken = False
+        self.replays = 0     # graph launches so far (bench.py reports whether its timed steps were replays)
+        self.captures = 0
+        self._params = None  # (epoch, [parameters]) - the list is rebuilt when the epoch moves
+
+    def _weight_stamp(self):
+        if self._params is None or self._params[0] != TensorKeyedCache.epoch:
+            self._params = (TensorKeyedCache.epoch, list(self.module.parameters()))
+        return hash(tuple((q.data_ptr(), q._version) for q in self._params[1]))
+
+    @property
+    def active(self) -> bool:
+        return not self.broken
+
+    def _held_state(self):
+        """Every step-invariant tensor the module tree caches OUTSIDE the graph pool (see the module docstring)."""
+        held = []
+        for m in self.module.modules():
+            kv = getattr(m, "_kv", None)
+            if kv is not None:
+                held.append(kv)
+            cc = getattr(m, "_ctx_cast", None)
+            if cc is not None:
+                held.append(cc)
+        return held
 
     def invalidate(self):
         self._graphs.clear()
@@ -50,20 +95,26 @@ class GraphedModule:
         if self.broken:
             return self.module(x, **kw)
         g = self._graphs.get(key)
+        if g is not None and g[5] != self._weight_stamp():  # weights changed since the capture: its packed images are stale
+            del self._graphs[key]
+            g = None
         if g is None:
             try:
                 g = self._capture(key, x, dyn, consts, other)
-            except Exception as e:  # capture is an optimisation: fall back to eager launches of the same kernels
+            except Exception as e:
+                if self.strict:
+                    raise L.CrgError(f"hipGraph capture failed ({type(e).__name__}: {e})") from e
                 import warnings
                 warnings.warn(f"hipGraph capture failed ({type(e).__name__}: {e}); continuing with eager launches")
                 self.broken = True
                 torch.cuda.synchronize(x.device)
                 return self.module(x, **kw)
-        graph, sx, sdyn, sout, _keep = g
+        graph, sx, sdyn, sout = g[:4]
         sx.copy_(x)
         for k, v in dyn.items():
             sdyn[k].copy_(v)
         graph.replay()
+        self.replays += 1
         return sout.clone()
 
     def _capture(self, key, x, dyn, consts, other):
@@ -84,6 +135,9 @@ class GraphedModule:
         graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(graph):
             sout = self.module(sx, **sdyn, **consts, **other)
-        g = (graph, sx, sdyn, sout, consts)  # `consts` kept alive: their storage backs the cached K/V inside the graph
+        # held: the conditioning and the modules' K / V^T / cast-context caches as they are RIGHT NOW (filled by the warm-up,
+        # read by the captured kernels); stamp: the weights this capture baked in
+        g = (graph, sx, sdyn, sout, (consts, self._held_state()), self._weight_stamp())
         self._graphs[key] = g
+        self.captures += 1
         return g

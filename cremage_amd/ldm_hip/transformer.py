@@ -10,7 +10,8 @@ What differs is only HOW forward computes:
   * tokens stay [B, HW, C] = the channels-last image itself: no `b c h w -> b (hw) c` copies
     (attention.py:1045,1048);
   * q/k/v/out, proj_in/out, GEGLU and net.2 are MFMA GEMMs with bias / residual / GEGLU fused in the
-    epilogue; V is produced already transposed for the flash kernel;
+    epilogue; in bf16 the projections that share an input (q|k|v of self-attention, k|v of the context) are ONE
+    launch over row-stacked weights and the flash kernel reads V row-major (transposing LDS read);
   * softmax(QK^T)V is one flash-style kernel, never materialising the N x N scores;
   * LoRA branches (attention.py:88-96,157-168,616-641,685-692,1038-1056) are folded into an
     effective weight W + sum_i w_i (alpha_i / r_i) Up_i Down_i when the packed weight is (re)built;
@@ -159,45 +160,71 @@ class CrossAttention(nn.Module):
             self.to_v_ipa = Linear(context_dim, inner_dim, bias=False)
         self._kv = None  # (context tensor object, version, weight keys, k, vt, [k_ipa, vt_ipa])
 
+    def _fused(self, dtype: torch.dtype) -> bool:
+        """bf16 with a head dim the flash kernel takes: projections that share an input are ONE GEMM over row-stacked weights
+        and V stays row-major (ops.attention_rows_v); otherwise (fp32-class) the separate / transposed-V projections."""
+        return dtype == torch.bfloat16 and (self.to_q.weight.shape[0] // self.heads) <= 160
+
+    @staticmethod
+    def _stack(*ws):
+        hit = _qk_cache.get(ws)
+        if hit is None:
+            with torch.no_grad():
+                hit = _qk_cache.put(ws, (), torch.cat([w.detach() for w in ws], 0).contiguous())
+        return hit
+
     def _project_kv(self, context: torch.Tensor, dtype: torch.dtype):
         wk, wv = _eff(self, self.to_k.weight, "k"), _eff(self, self.to_v.weight, "v")
-        wkeys = (_tkey(wk), _tkey(wv), dtype)
+        fused = self._fused(dtype)
+        wkeys = (_tkey(wk), _tkey(wv), dtype, fused)
         c = self._kv
         if c is not None and c[0] is context and c[1] == context._version and c[2] == wkeys:
             return c[3]
         ctx = context if context.dtype == dtype else context.to(dtype)
         ipa = None
+        C_ = wk.shape[0]
         if self.ipa_num_tokens > 0:  # attention.py:623-627: last tokens go to the FaceID K/V projections
             end = ctx.shape[1] - self.ipa_num_tokens
             ctx, ipa_ctx = ctx[:, :end].contiguous(), ctx[:, end:].contiguous()
-            ipa = (ops.linear(ipa_ctx, self.to_k_ipa.weight), ops.linear_transposed(ipa_ctx, self.to_v_ipa.weight), ipa_ctx.shape[1])
-        out = (ops.linear(ctx, wk), ops.linear_transposed(ctx, wv), ctx.shape[1], ipa)
+            if fused:
+                kv = ops.linear(ipa_ctx, self._stack(self.to_k_ipa.weight, self.to_v_ipa.weight))
+                ipa = (kv[..., :C_], kv[..., C_:], ipa_ctx.shape[1])
+            else:
+                ipa = (ops.linear(ipa_ctx, self.to_k_ipa.weight), ops.linear_transposed(ipa_ctx, self.to_v_ipa.weight), ipa_ctx.shape[1])
+        if fused:
+            kv = ops.linear(ctx, self._stack(wk, wv))   # [b, m, 2C]: K | V, both row-major
+            out = (kv[..., :C_], kv[..., C_:], ctx.shape[1], ipa)
+        else:
+            out = (ops.linear(ctx, wk), ops.linear_transposed(ctx, wv), ctx.shape[1], ipa)
         self._kv = (context, context._version, wkeys, out)
         return out
 
     def forward(self, x, context=None, mask=None, residual=None):
         if exists(mask):
             raise NotImplementedError("attention masks are never passed on the SD path (attention.py:648-652)")
+        fused = self._fused(x.dtype)
         if context is None:
-            # self-attention: Q and K projections share their input -> one GEMM with the two weights stacked
-            wq, wk = _eff(self, self.to_q.weight, "q"), _eff(self, self.to_k.weight, "k")
-            wqk = _qk_cache.get((wq, wk))
-            if wqk is None:
-                with torch.no_grad():
-                    wqk = _qk_cache.put((wq, wk), (), torch.cat([wq.detach(), wk.detach()], 0).contiguous())
-            qk = ops.linear(x, wqk)
+            wq, wk, wv = _eff(self, self.to_q.weight, "q"), _eff(self, self.to_k.weight, "k"), _eff(self, self.to_v.weight, "v")
             c = wq.shape[0]
-            q, k = qk[..., :c], qk[..., c:]
-            vt = ops.linear_transposed(x, _eff(self, self.to_v.weight, "v"))
-            nk, ipa = x.shape[1], None
             if self.ipa_num_tokens > 0:
                 raise NotImplementedError("ipa_num_tokens > 0 needs a context (attention.py:623-627)")
+            if fused:
+                # self-attention: the three projections share their input -> ONE GEMM, q / k / v are column slices of its output
+                qkv = ops.linear(x, self._stack(wq, wk, wv))
+                out = ops.attention_rows_v(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads, self.scale)
+                return ops.linear(out, _eff(self, self.to_out[0].weight, "out"), self.to_out[0].bias, residual=residual)
+            qk = ops.linear(x, self._stack(wq, wk))
+            q, k = qk[..., :c], qk[..., c:]
+            vt = ops.linear_transposed(x, wv)
+            nk, ipa = x.shape[1], None
         else:
             q = ops.linear(x, _eff(self, self.to_q.weight, "q"))
             k, vt, nk, ipa = self._project_kv(context, x.dtype)
-        out = ops.attention(q, k, vt, self.heads, nk, self.scale)
+        att = (lambda kk, vv, n: ops.attention_rows_v(q, kk, vv, self.heads, self.scale)) if fused else \
+              (lambda kk, vv, n: ops.attention(q, kk, vv, self.heads, n, self.scale))
+        out = att(k, vt, nk)
         if ipa is not None:  # attention.py:660-681
-            out_ipa = ops.attention(q, ipa[0], ipa[1], self.heads, ipa[2], self.scale)
+            out_ipa = att(ipa[0], ipa[1], ipa[2])
             ops.axpby_(out, out_ipa, float(self.ipa_scale), 1.0)
         return ops.linear(out, _eff(self, self.to_out[0].weight, "out"), self.to_out[0].bias, residual=residual)
 

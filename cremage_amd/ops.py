@@ -105,7 +105,13 @@ class TensorKeyedCache:
             d.pop(key, None)
 
         self._d[key] = (tuple(weakref.ref(t, _drop) for t in tensors), tuple(self._stamp(t) for t in tensors), value)
+        TensorKeyedCache.epoch += 1
         return value
+
+    # bumped whenever ANY derived weight image is (re)built: captured hipGraphs bake the addresses of the images they were
+    # captured with, so cremage_amd.graphs drops a graph whose capture-time epoch is stale (load_state_dict, LoRA setattr and
+    # .to() all land here through their cache miss)
+    epoch = 0
 
     def clear(self):
         self._d.clear()
@@ -488,6 +494,31 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, n_
               w_bstride=Dh * ld, bias=None, bias_mode=L.BIAS_NONE, residual=None, ldr=0, r_bstride=0, y=o[b].data_ptr(), ldy=Cc,
               y_bstride=Dh, M=Nq, N=Dh, K=kp, batch=heads, epilogue=L.EPI_NONE, a_dtype=L.F32, y_dtype=_act_dt(q), prec=prec,
               a_is_weight=0, a_lo=None)
+    return o
+
+
+def attention_rows_v(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """softmax(Q K^T * scale) V with V ROW-MAJOR ([B, Nk, C], like K): q, k, v may be column slices of one fused projection
+    output (rows keep the parent's stride), which is what makes `to_q | to_k | to_v` ONE GEMM launch.  bf16, d_head <= 160
+    (crg_attention_v: the flash kernel transposes V on its LDS read)."""
+    _need_cuda(q, k, v)
+    B, Nq, Cc = q.shape
+    Nk = k.shape[1]
+    Dh = Cc // heads
+    if q.dtype != torch.bfloat16 or Dh > 160 or k.shape != v.shape or k.shape[0] != B or k.shape[2] != Cc:
+        raise L.CrgError("attention_rows_v: bf16 q / k / v with matching shapes and d_head <= 160 expected")
+
+    def rows(t):
+        if t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+            t = t.contiguous()
+        return t, t.stride(1)
+    q, ldq = rows(q)
+    k, ldk = rows(k)
+    v, ldv = rows(v)
+    o = torch.empty((B, Nq, Cc), dtype=q.dtype, device=q.device)
+    h = _h(q)
+    L.check(L.load().crg_attention_v(h, _st(), _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(o), Cc, B, heads, Nq, Nk, Dh, scale, L.BF16), h,
+            "crg_attention_v")
     return o
 
 

@@ -183,3 +183,31 @@ def img2img_sdxl(eng, init_image: torch.Tensor, c: dict, uc: dict, *, steps: int
         return None, samples
     x = eng.decode_first_stage(samples)
     return ops.affine_cast(x, 0.5, 0.5, torch.float32, 0.0, 1.0), samples
+
+
+@torch.no_grad()
+def txt2img_sdxl_facefix(eng, c: dict, uc: dict, boxes, *, steps: int = 30, cfg_scale: float = 5.0, height: int = 1024, width: int = 1024,
+                         fix_size: Optional[int] = None, strength: float = 0.3, x0: Optional[torch.Tensor] = None,
+                         enc_noise: Optional[torch.Tensor] = None, fwd_noise: Optional[torch.Tensor] = None, paste: bool = True):
+    """BASELINE config 5: SDXL txt2img, then the auto-face-fix second pass on one region per image - the UNet RE-ENTRY on a crop.
+
+    Reference flow (modules/sdxl/sdxl_pipeline/sdxl_image_generator_utils.py:559-772 txt2img, then per detected face
+    modules/face_detection/face_img2img.py:57-235 -> do_img2img :906-1025): crop the face box, bring the crop to the generation
+    size, img2img it with strength 0.3 (encode -> noise to sigma_0 of the pruned schedule -> Euler-EDM over the last
+    int(0.3 * steps) sigmas -> decode), bring it back to the box size and paste it over the first-pass image.
+    In scope here is the numeric path (both UNet passes, VAE encode / decode); the glue around it is deliberately plain PyTorch:
+    `boxes` = one (top, left, size) per image instead of the face detector (out of scope), the two resizes are
+    F.interpolate(bilinear, antialias off) instead of cv2 Lanczos (not built), the paste is a hard-edged copy.
+    Returns (final images [b,3,H,W] in [0,1], first-pass images, second-pass crops at `fix_size`)."""
+    import torch.nn.functional as F
+    first, _ = txt2img_sdxl(eng, c, uc, steps=steps, cfg_scale=cfg_scale, height=height, width=width, x0=x0)
+    fix = fix_size or height
+    crops = torch.stack([F.interpolate(first[i:i + 1, :, t:t + sz, l:l + sz], size=(fix, fix), mode="bilinear", align_corners=False)[0]
+                         for i, (t, l, sz) in enumerate(boxes)])
+    fixed, _ = img2img_sdxl(eng, crops * 2.0 - 1.0, c, uc, steps=steps, strength=strength, cfg_scale=cfg_scale, enc_noise=enc_noise,
+                            fwd_noise=fwd_noise)
+    out = first.clone()
+    if paste:
+        for i, (t, l, sz) in enumerate(boxes):
+            out[i, :, t:t + sz, l:l + sz] = F.interpolate(fixed[i:i + 1], size=(sz, sz), mode="bilinear", align_corners=False)[0]
+    return out, first, fixed

@@ -20,14 +20,17 @@ from torch import nn
 
 
 def append_zero(x):
-    return torch.cat([x, x.new_zeros([1])])
+    """x followed by one 0 (the terminal sigma of every k-diffusion schedule)."""
+    out = x.new_zeros(x.shape[0] + 1)
+    out[:-1] = x
+    return out
 
 
 def append_dims(x, target_dims):
-    dims_to_append = target_dims - x.ndim
-    if dims_to_append < 0:
-        raise ValueError(f'input has {x.ndim} dims but target_dims is {target_dims}, which is less')
-    return x[(...,) + (None,) * dims_to_append]
+    """Per-sample vector -> broadcastable against a tensor of `target_dims` dims (trailing singleton axes)."""
+    if x.ndim > target_dims:
+        raise ValueError(f"cannot view a {x.ndim}-d tensor as {target_dims}-d")
+    return x.reshape(tuple(x.shape) + (1,) * (target_dims - x.ndim))
 
 
 def make_beta_schedule(schedule="linear", n_timestep=1000, linear_start=0.00085, linear_end=0.012):
@@ -45,67 +48,68 @@ def make_alphas_cumprod(n_timestep=1000, linear_start=0.00085, linear_end=0.012)
 
 
 class DiscreteSchedule(nn.Module):
-    """external.py:41-84."""
+    """The sigma table of a discrete-time model and the two maps between sigma and (fractional) timestep.
+
+    Behaviour of k_diffusion `DiscreteSchedule` (external.py:41-84), pinned by tests/golden/schedules.npz; the code is this
+    repo's own: one ascending fp32 table `log_sigmas` (a buffer, so `.to(device)` moves it) and linear interpolation in
+    log-sigma between neighbouring integer timesteps."""
 
     def __init__(self, sigmas, quantize):
         super().__init__()
-        self.register_buffer('sigmas', sigmas)
-        self.register_buffer('log_sigmas', sigmas.log())
+        table = sigmas.detach().clone()
+        self.register_buffer("sigmas", table)
+        self.register_buffer("log_sigmas", table.log())
         self.quantize = quantize
 
-    @property
-    def sigma_min(self):
-        return self.sigmas[0]
+    sigma_min = property(lambda self: self.sigmas[0])
+    sigma_max = property(lambda self: self.sigmas[-1])
 
-    @property
-    def sigma_max(self):
-        return self.sigmas[-1]
-
-    def get_sigmas(self, n=None):
-        if n is None:
-            return append_zero(self.sigmas.flip(0))
-        t_max = len(self.sigmas) - 1
-        t = torch.linspace(t_max, 0, n, device=self.sigmas.device)
-        return append_zero(self.t_to_sigma(t))
-
-    def sigma_to_t(self, sigma, quantize=None):
-        quantize = self.quantize if quantize is None else quantize
-        log_sigma = sigma.log()
-        if quantize:
-            dists = log_sigma - self.log_sigmas[:, None]
-            return dists.abs().argmin(dim=0).view(sigma.shape)
-        # external.py:71 writes `dists.ge(0).cumsum(dim=0).argmax(dim=0)`: the index of the last table entry
-        # <= log_sigma (0 when there is none).  log_sigmas is ascending, so that is a binary search - same
-        # integers, without the [1000, b] cumsum kernel every step.
-        low_idx = (torch.searchsorted(self.log_sigmas, log_sigma.contiguous(), right=True) - 1).clamp(min=0, max=self.log_sigmas.shape[0] - 2)
-        high_idx = low_idx + 1
-        low, high = self.log_sigmas[low_idx], self.log_sigmas[high_idx]
-        w = (low - log_sigma) / (low - high)
-        w = w.clamp(0, 1)
-        t = (1 - w) * low_idx + w * high_idx
-        return t.view(sigma.shape)
+    def _blend(self, idx_lo, idx_hi, frac):
+        """(1 - frac) * log_sigmas[idx_lo] + frac * log_sigmas[idx_hi], the one interpolation rule both maps share."""
+        lo, hi = self.log_sigmas[idx_lo], self.log_sigmas[idx_hi]
+        return (1 - frac) * lo + frac * hi
 
     def t_to_sigma(self, t):
         t = t.float()
-        low_idx, high_idx, w = t.floor().long(), t.ceil().long(), t.frac()
-        log_sigma = (1 - w) * self.log_sigmas[low_idx] + w * self.log_sigmas[high_idx]
-        return log_sigma.exp()
+        below = t.floor()
+        return self._blend(below.long(), t.ceil().long(), t - below).exp()
+
+    def get_sigmas(self, n=None):
+        """n sigmas from the table's largest to its smallest timestep (evenly spaced in t), then 0; the whole table reversed
+        when n is None."""
+        if n is None:
+            return append_zero(torch.flip(self.sigmas, dims=(0,)))
+        last = self.sigmas.shape[0] - 1
+        return append_zero(self.t_to_sigma(torch.linspace(last, 0, n, device=self.sigmas.device)))
+
+    def sigma_to_t(self, sigma, quantize=None):
+        if quantize is None:
+            quantize = self.quantize
+        ls = sigma.log()
+        if quantize:  # nearest table entry in log-sigma
+            return (ls.reshape(1, -1) - self.log_sigmas.reshape(-1, 1)).abs().argmin(dim=0).reshape(sigma.shape)
+        # the table is ascending: the bracketing pair is found by binary search (index of the last entry <= log sigma, clamped
+        # so that there is always an upper neighbour); out-of-table sigmas clamp to the end timesteps
+        n = self.log_sigmas.shape[0]
+        lo = (torch.searchsorted(self.log_sigmas, ls.contiguous(), right=True) - 1).clamp(min=0, max=n - 2)
+        a, b = self.log_sigmas[lo], self.log_sigmas[lo + 1]
+        frac = ((a - ls) / (a - b)).clamp(0, 1)
+        return ((1 - frac) * lo + frac * (lo + 1)).reshape(sigma.shape)
 
 
 class CompVisDenoiser(DiscreteSchedule):
-    """DiscreteEpsDDPMDenoiser + CompVisDenoiser (external.py:87-147): sigma = sqrt((1-a)/a);
-    forward: eps = model.apply_model(x * c_in, sigma_to_t(sigma), **kw); return x + eps * (-sigma)."""
+    """eps-prediction wrapper of a CompVis LatentDiffusion (k_diffusion external.py:87-147): sigma_t = sqrt((1 - a_t) / a_t),
+    eps = model.apply_model(x / sqrt(sigma^2 + 1), sigma_to_t(sigma), ...), denoised = x - sigma * eps."""
 
     def __init__(self, model, quantize=False, device='cpu'):
-        alphas_cumprod = model.alphas_cumprod
-        super().__init__(((1 - alphas_cumprod) / alphas_cumprod) ** 0.5, quantize)
+        acp = model.alphas_cumprod
+        super().__init__(((1 - acp) / acp) ** 0.5, quantize)
         self.inner_model = model
         self.sigma_data = 1.
 
     def get_scalings(self, sigma):
-        c_out = -sigma
-        c_in = 1 / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
-        return c_out, c_in
+        """(c_out, c_in) of the eps parameterisation."""
+        return -sigma, 1 / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
 
     def get_eps(self, *args, **kwargs):
         return self.inner_model.apply_model(*args, **kwargs)

@@ -180,6 +180,12 @@ int crg_pack_geglu_bias(crg_ctx* ctx, void* stream, const float* src, int n_out2
 int crg_attention(crg_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k, int64_t ldk,
                   const void* vt, int64_t ldvt, void* o, int64_t ldo, int B, int H, int Nq, int Nk, int Dh,
                   float scale, int dtype);
+/* Same attention with V ROW-MAJOR: v: [B][Nk][ldv] (head h at column h*Dh) - the layout of a fused Q|K|V (or K|V) projection
+ * output, so that `to_q / to_k / to_v` of a self-attention (attention.py:614,629,636) are ONE GEMM launch over stacked
+ * weights and q, k, v are column slices of its output (ldq = ldk = ldv = 3*H*Dh).  The kernel transposes V on the LDS read. */
+int crg_attention_v(crg_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                    const void* v, int64_t ldv, void* o, int64_t ldo, int B, int H, int Nq, int Nk, int Dh,
+                    float scale, int dtype);
 
 /* ---- row softmax (VAE AttnBlock, model.py:197-199: softmax(w * c^-0.5, dim=2)) ----------------
  * x,y: [rows][cols] of `dtype` (in place allowed), y = softmax(x * scale) per row. */

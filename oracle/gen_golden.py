@@ -735,12 +735,174 @@ def g_sgm_img2img():
          sigmas=sigmas, z=z, noised_z=noised_z, x=x, img=out)
 
 
+def g_sgm_vae():
+    """The SDXL first stage as the reference builds it (sd_xl_base.yaml:77-92 -> sgm/modules/diffusionmodules/model.py:
+    Encoder :492-612, Decoder :614-760, AttnBlock :161-195, make_attn :277-309).  attn_type: the YAML asks for
+    "vanilla-xformers" (MemoryEfficientAttnBlock, :198-266), which needs the absent xformers package; "vanilla" builds AttnBlock -
+    the same parameters (norm, q, k, v, proj_out) and the same single-head softmax(q k^T / sqrt(C)) v through SDPA - so the
+    fixtures are generated with it and the HIP path is checked with BOTH attn_type spellings against them."""
+    _import_sgm()
+    from sgm.modules.diffusionmodules import model as SV
+    from ldm.modules.distributions.distributions import DiagonalGaussianDistribution as DG
+
+    def build(dd):
+        enc, dec = SV.Encoder(**dd), SV.Decoder(**dd)
+        qc, pqc = torch.nn.Conv2d(2 * dd["z_channels"], 2 * 4, 1), torch.nn.Conv2d(4, dd["z_channels"], 1)
+        box = torch.nn.Module()  # same key layout as AutoencoderKL: encoder.*, decoder.*, quant_conv.*, post_quant_conv.*
+        box.encoder, box.decoder, box.quant_conv, box.post_quant_conv = enc, dec, qc, pqc
+        synth_fill_(box, SEED, prefix="vae.")
+        return box.eval()
+
+    dd = dict(TINY_DD, attn_type="vanilla")
+    ae = build(dd)
+    z = synth_input("sgm_vae_tiny.z", (2, 4, 8, 8), SEED)
+    img = synth_input("sgm_vae_tiny.img", (2, 3, 16, 16), SEED, 0.5).clamp(-1, 1)
+    noise = synth_input("sgm_vae_tiny.noise", (2, 4, 8, 8), SEED)
+    with fp32_forward():
+        dec = ae.decoder(ae.post_quant_conv(z))
+        moments = ae.quant_conv(ae.encoder(img))
+        post = DG(moments)
+        sample = post.mean + post.std * noise
+    import hashlib
+    items = sorted(f"{k}:{tuple(v.shape)}" for k, v in ae.state_dict().items())
+    save("sgm_vae_tiny", dict(dd=dd, seed=SEED, prefix="vae.", n_keys=len(items), keys_sha1=hashlib.sha1("\n".join(items).encode()).hexdigest()),
+         dec=dec, moments=moments, sample=sample)
+
+
+def g_sgm_vae_full():
+    """Full-size SDXL VAE (sd_xl_base.yaml ddconfig) decode of a 128x128 latent -> 1024x1024 (fp32, as the reference runs it:
+    sd_xl_base.yaml:5 disable_first_stage_autocast), kept as an fp16 image of every 8th pixel row / column plus the exact
+    fp32 values on a 16x coarser grid, and an encode at 256x256."""
+    _import_sgm()
+    from sgm.modules.diffusionmodules import model as SV
+    dd = dict(SD15_DD, attn_type="vanilla")
+    box = torch.nn.Module()
+    box.encoder, box.decoder = SV.Encoder(**dd), SV.Decoder(**dd)
+    box.quant_conv, box.post_quant_conv = torch.nn.Conv2d(8, 8, 1), torch.nn.Conv2d(4, 4, 1)
+    synth_fill_(box, SEED, prefix="vae.")
+    box.eval()
+    z = synth_input("sgm_vae_full.z", (1, 4, 128, 128), SEED)
+    t0 = time.time()
+    with fp32_forward():
+        dec = box.decoder(box.post_quant_conv(z / 0.13025))
+    dt = time.time() - t0
+    x = synth_input("sgm_vae_full.img", (1, 3, 256, 256), SEED, 0.5).clamp(-1, 1)
+    with fp32_forward():
+        moments = box.quant_conv(box.encoder(x))
+    save("sgm_vae_full", dict(dd=dd, seed=SEED, prefix="vae.", ref_cpu_seconds=dt, threads=torch.get_num_threads(), scale_factor=0.13025, hw=256),
+         dec_sub8_f16=dec[:, :, ::8, ::8].half(), dec_sub16=dec[:, :, ::16, ::16].contiguous(),
+         dec_stats=torch.tensor([dec.mean().item(), dec.std().item(), dec.abs().max().item()]), moments=moments)
+
+
+def g_c1_sd15_full_trajectory():
+    """BASELINE.json configs[0] ("C1") at FULL size: SD1.5 txt2img 512x512, batch 1, 20-step Euler, CFG 7.5, fp32 on the CPU,
+    through the reference's own stack (EulerSampler -> k_diffusion.sample_euler -> LDMWrapperForKDiffusion (CFG batch doubling)
+    -> CompVisDenoiser -> LatentDiffusion.apply_model -> DiffusionWrapper -> UNetModel, 859.52 M parameters) and
+    decode_first_stage with the full 49.49 M-parameter decoder.  The final latent, a few latents on the way (the drift of a
+    bf16 run is a function of the step) and the image (every 8th pixel exact, all pixels as fp16) are the fixture the GPU
+    path's accumulated 20-step error is measured against (north_star: "stated fp32 per-pixel tolerance")."""
+    ldm = LatentDiffusion(first_stage_config={"target": "ldm.models.autoencoder.AutoencoderKL",
+                                              "params": dict(ddconfig=SD15_DD, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4)},
+                          cond_stage_config={"target": "torch.nn.Identity"},
+                          unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": SD15_UNET},
+                          linear_start=0.00085, linear_end=0.012, timesteps=1000, conditioning_key="crossattn",
+                          scale_factor=0.18215, use_ema=False, cond_stage_trainable=False, first_stage_key="jpg",
+                          cond_stage_key="txt", image_size=64, channels=4)
+    synth_fill_(ldm.model.diffusion_model, SEED, prefix="unet.")
+    synth_fill_(ldm.first_stage_model, SEED, prefix="vae.")
+    ldm.eval()
+    B, L, S = 1, 64, 20
+    c = synth_input("c1.c", (B, 77, 768), SEED)
+    uc = synth_input("c1.uc", (B, 77, 768), SEED)
+    x0 = synth_input("c1.x0", (B, 4, L, L), SEED)
+    R_ks.trange = R_ksamp.trange = lambda *a, **k: range(*a)
+    s = R_ks.EulerSampler(ldm)
+    mids = {}
+    orig_model_call = R_kext.CompVisDenoiser.forward
+    calls = [0]
+
+    def spy(self, inp, sigma, **kw):  # records the latent that enters UNet call i (B = 2: CFG doubling) - no arithmetic changed
+        i = calls[0]
+        if i in (5, 10, 15):
+            mids[i] = inp[:B].clone()
+        calls[0] += 1
+        return orig_model_call(self, inp, sigma, **kw)
+
+    R_kext.CompVisDenoiser.forward = spy
+    t0 = time.time()
+    try:
+        with fp32_forward(), contextlib.redirect_stdout(open(os.devnull, "w")):
+            s._sample_common_prep(S=S, batch_size=B, shape=[4, L, L], conditioning=c, unconditional_guidance_scale=7.5,
+                                  unconditional_conditioning=uc, x0=x0)
+            x, _ = s.do_sample()
+            t_unet = time.time() - t0
+            img = ldm.decode_first_stage(x)
+    finally:
+        R_kext.CompVisDenoiser.forward = orig_model_call
+    dt = time.time() - t0
+    pix = torch.clamp((img + 1.0) / 2.0, 0.0, 1.0)
+    save("traj_c1_sd15_full", dict(B=B, L=L, S=S, cfg=7.5, seed=SEED, unet=SD15_UNET, dd=SD15_DD, sampler="euler", ref_cpu_seconds=dt,
+                                   ref_cpu_seconds_unet=t_unet, threads=torch.get_num_threads(), unet_calls=calls[0]),
+         sigmas=s.sigmas, x=x, x5=mids[5], x10=mids[10], x15=mids[15], img_sub8=img[:, :, ::8, ::8].contiguous(), img_f16=img.half(),
+         pix_stats=torch.tensor([pix.mean().item(), pix.std().item(), img.abs().max().item()]))
+
+
+def g_c5_chain():
+    """BASELINE config 5 as ONE chain at tiny size, every numeric piece the reference's own: SDXL txt2img (EulerEDMSampler +
+    DiscreteDenoiser + VanillaCFG + sgm UNet, 5 steps) -> decode -> clamp((x+1)/2) -> crop a fixed box -> bilinear resize to
+    the generation size -> img2img re-entry (Img2ImgDiscretizationWrapper strength 0.3 over 10 steps = 3 UNet steps; encoder
+    moments -> posterior sample; Euler-EDM; decode) -> resize back -> paste.  The box replaces the face detector and the two
+    resizes are torch bilinear instead of cv2 Lanczos (both outside the numeric path; see pipeline.txt2img_sdxl_facefix)."""
+    import torch.nn.functional as F
+    SU, DN, DZ, GD, SM, WR = _import_sgm()
+    SM.denoising_status_queue = types.SimpleNamespace(put=lambda *a, **k: None)
+    from scripts.demo.discretization import Img2ImgDiscretizationWrapper
+    from ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+    unet = SU.UNetModel(**TINY_SGM_UNET)
+    synth_fill_(unet, SEED, prefix="sgm_unet.")
+    model = WR.OpenAIWrapper(unet)
+    disc = {"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"}
+    den = DN.DiscreteDenoiser(scaling_config={"target": "sgm.modules.diffusionmodules.denoiser_scaling.EpsScaling"}, num_idx=1000,
+                              discretization_config=disc)
+    guider = {"target": "sgm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 5.0}}
+    B, L, S1, S2, strength = 2, 16, 5, 10, 0.3
+    boxes = [(4, 6, 16), (12, 8, 16)]  # (top, left, size) in the 32x32 first-pass image
+    c = {"crossattn": synth_input("c5.c", (B, 77, 128), SEED), "vector": synth_input("c5.cv", (B, 96), SEED)}
+    uc = {"crossattn": synth_input("c5.uc", (B, 77, 128), SEED), "vector": synth_input("c5.ucv", (B, 96), SEED)}
+    x0 = synth_input("c5.x0", (B, 4, L, L), SEED)
+    enc_noise = synth_input("c5.enc_noise", (B, 4, L, L), SEED)
+    noise = synth_input("c5.noise", (B, 4, L, L), SEED)
+    ae = _make_ae(TINY_DD)
+    with fp32_forward(), contextlib.redirect_stdout(open(os.devnull, "w")):
+        smp = SM.EulerEDMSampler(discretization_config=disc, num_steps=S1, guider_config=guider, device="cpu")
+        x1 = smp(lambda inp, sigma, cc: den(model, inp, sigma, cc), x0.clone(), cond=c, uc=uc)
+        first = torch.clamp((ae.decode(x1 / 0.13025) + 1.0) / 2.0, 0.0, 1.0)
+        crops = torch.stack([F.interpolate(first[i:i + 1, :, t:t + sz, l:l + sz], size=(2 * L, 2 * L), mode="bilinear", align_corners=False)[0]
+                             for i, (t, l, sz) in enumerate(boxes)])
+        smp2 = SM.EulerEDMSampler(discretization_config=disc, num_steps=S2, guider_config=guider, device="cpu")
+        smp2.discretization = Img2ImgDiscretizationWrapper(smp2.discretization, strength=strength)
+        post = DiagonalGaussianDistribution(ae.quant_conv(ae.encoder(crops * 2.0 - 1.0)))
+        z = 0.13025 * (post.mean + post.std * enc_noise)
+        sigmas = smp2.discretization(smp2.num_steps)
+        noised_z = (z + noise * sigmas[0]) / torch.sqrt(1.0 + sigmas[0] ** 2.0)
+        x2 = smp2(lambda inp, sigma, cc: den(model, inp, sigma, cc), noised_z.clone(), cond=c, uc=uc)
+        fixed = torch.clamp((ae.decode(x2 / 0.13025) + 1.0) / 2.0, 0.0, 1.0)
+        out = first.clone()
+        for i, (t, l, sz) in enumerate(boxes):
+            out[i, :, t:t + sz, l:l + sz] = F.interpolate(fixed[i:i + 1], size=(sz, sz), mode="bilinear", align_corners=False)[0]
+    save("traj_c5_chain", dict(B=B, L=L, S1=S1, S2=S2, strength=strength, cfg=5.0, seed=SEED, unet=TINY_SGM_UNET, dd=TINY_DD,
+                               scale_factor=0.13025, boxes=boxes, second_pass_sigmas=len(sigmas)),
+         x1=x1, first=first, z=z, x2=x2, fixed=fixed, out=out)
+
+
 CASES = dict(alphas_doc=g_alphas_doc, param_contract=g_param_contract, groupnorm=g_groupnorm, timestep_embedding=g_timestep_embedding, resblock=g_resblock, updown=g_updown,
              attention=g_attention, transformer=g_transformer, unet_tiny=g_unet_tiny, unet_small_sd=g_unet_small_sd,
              vae_blocks=g_vae_blocks, vae_tiny=g_vae_tiny, schedules=g_schedules, trajectories=g_trajectories, hires_latent=g_hires_latent)
 CASES.update(controlnet_hook=g_controlnet_hook, controlnet=g_controlnet)
-CASES.update(sgm_unet_tiny=g_sgm_unet_tiny, sgm_unet_small=g_sgm_unet_small, sgm_trajectory=g_sgm_trajectory, sgm_img2img=g_sgm_img2img)
-FULL = dict(controlnet_sd15_full=g_controlnet_sd15_full, unet_sd15_full=g_unet_sd15_full, vae_sd15_full=g_vae_sd15_full, sgm_unet_full=g_sgm_unet_full)
+CASES.update(sgm_unet_tiny=g_sgm_unet_tiny, sgm_unet_small=g_sgm_unet_small, sgm_trajectory=g_sgm_trajectory, sgm_img2img=g_sgm_img2img,
+             sgm_vae=g_sgm_vae, c5_chain=g_c5_chain)
+FULL = dict(controlnet_sd15_full=g_controlnet_sd15_full, unet_sd15_full=g_unet_sd15_full, vae_sd15_full=g_vae_sd15_full, sgm_unet_full=g_sgm_unet_full,
+            sgm_vae_full=g_sgm_vae_full, c1_sd15_full_trajectory=g_c1_sd15_full_trajectory)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -132,3 +132,44 @@ def test_full_state_dict_contract_sha1():
     assert digest(u) == (meta["unet_sha1"], meta["unet_n"])
     assert digest(ul) == (meta["unet_lora_sha1"], meta["unet_lora_n"])
     assert digest(ae) == (meta["vae_sha1"], meta["vae_n"])
+
+
+def test_reference_side_container_proof():
+    """tests/golden/reference_container.json is written by oracle/check_reference_container.py in the build container: the
+    REFERENCE's instantiate_from_config (ldm/util.py:81-96) built the reference's own LatentDiffusion / ControlLDM from this repo's
+    *-hip.yaml files and the reference's `load_state_dict(sd, strict=False)` (image_generator.py:345) loaded reference-named keys
+    into them.  Here (no reference needed): nothing was missing or unexpected, and the key-list digest recorded for the HIP classes
+    inside that container is the digest of the classes as they are NOW (so the record cannot go stale silently)."""
+    import hashlib
+    import json
+    rec = json.load(open(os.path.join(REPO, "tests", "golden", "reference_container.json")))
+
+    def digest(sd):
+        items = sorted(f"{k}:{tuple(v.shape)}" for k, v in sd.items())
+        return hashlib.sha1("\n".join(items).encode()).hexdigest(), len(items)
+
+    assert rec["sd15"]["container"] == "ldm.models.diffusion.ddpm.LatentDiffusion"
+    assert rec["cldm"]["container"] == "cldm.cldm.ControlLDM"
+    for tag in ("sd15", "cldm"):
+        r = rec[tag]
+        assert r["missing_keys"] == [] and r["unexpected_keys"] == [], (tag, r["missing_keys"][:5], r["unexpected_keys"][:5])
+        assert r["sha1_ref"] == r["sha1_hip"] and r["n_keys_ref"] == r["n_keys_hip"]
+        assert all(t.startswith("cremage_amd.") for t in r["hip_targets"]) and len(r["hip_targets"]) >= 2
+    for part in ("network_config", "first_stage_config"):
+        r = rec["sdxl"][part]
+        assert r["missing_keys"] == [] and r["unexpected_keys"] == [] and r["sha1_ref"] == r["sha1_hip"], part
+    # the HIP classes today, from the same YAML files, on the meta device (structure only)
+    from cremage_amd.ldm_hip.latent_diffusion import instantiate_from_config
+    cfgd = os.path.join(REPO, "cremage_amd", "configs")
+    p15 = yaml.safe_load(open(os.path.join(cfgd, "v1-inference-hip.yaml")))["model"]["params"]
+    pxl = yaml.safe_load(open(os.path.join(cfgd, "sd_xl_base-hip.yaml")))["model"]["params"]
+    with torch.device("meta"):
+        unet = instantiate_from_config(p15["unet_config"])
+        vae = instantiate_from_config(p15["first_stage_config"])
+        xl_unet = instantiate_from_config(pxl["network_config"])
+        xl_vae = instantiate_from_config(pxl["first_stage_config"])
+    assert digest(xl_unet.state_dict()) == (rec["sdxl"]["network_config"]["sha1_hip"], rec["sdxl"]["network_config"]["n_keys_hip"])
+    assert digest(xl_vae.state_dict()) == (rec["sdxl"]["first_stage_config"]["sha1_hip"], rec["sdxl"]["first_stage_config"]["n_keys_hip"])
+    # SD1.5 container keys = model.diffusion_model.* + first_stage_model.* (+ the schedule buffers of LatentDiffusion itself)
+    n_model = len(unet.state_dict()) + len(vae.state_dict())
+    assert 0 < rec["sd15"]["n_keys_hip"] - n_model < 40, (rec["sd15"]["n_keys_hip"], n_model)

@@ -333,6 +333,29 @@ def test_group_norm(dtype, C, hw, eps, silu):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tag", ["gn32_e5", "gn32_e5_c320", "gn_e6"])
+def test_group_norm_golden(dtype, tag):
+    """crg_groupnorm against the fixtures the reference's own GroupNorm32 (util.py:199-216, eps 1e-5) and Normalize
+    (attention.py:189-190, eps 1e-6) produced, with and without the fused SiLU (openaimodel.py:205-209)."""
+    from cremage_amd import ops
+    from cremage_amd.synth import synth_input
+    from tests.conftest import load_golden, synth_state_dict
+    meta, g = load_golden("op_" + tag)
+    C, hw = meta["C"], meta["hw"]
+    x = synth_input(tag, (2, C, hw, hw), meta["seed"], 1.5) + 0.3
+    sd = synth_state_dict(torch.nn.GroupNorm(32, C), meta["seed"], meta["prefix"])
+    w, b = sd["weight"].to(_dev()), sd["bias"].to(_dev())
+    for silu, key in ((False, "y"), (True, "y_silu")):
+        got = ops.group_norm(nhwc(x, dtype), w, b, 32, meta["eps"], silu=silu)
+        ref = g[key]
+        err = (got.float().cpu() - ref).abs().max().item()
+        # bf16: the input itself is rounded to 8 bits before the statistics (|x| <= ~5 -> 2e-2 of output units after the 1/sigma gain)
+        assert err < (2e-5 if dtype == torch.float32 else 6e-2), (tag, silu, err)
+        rel = ((got.float().cpu() - ref).norm() / ref.norm()).item()
+        assert rel < (1e-5 if dtype == torch.float32 else 6e-3), (tag, silu, rel)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_group_norm_concat(dtype):
     from cremage_amd import ops
     x1, x2 = rnd(2, 320, 6, 6, seed=53), rnd(2, 640, 6, 6, seed=54) * 2 + 1
@@ -394,6 +417,43 @@ def test_flash_attention(heads, d, Nq, Nk):
     got, ref = got.float().cpu(), ref
     rel = ((got - ref).norm() / ref.norm()).item()
     assert torch.isfinite(got).all() and rel < 1e-2, (rel, heads, d, Nq, Nk)
+
+
+@pytest.mark.parametrize("heads,d,Nq,Nk", [(8, 40, 200, 77), (8, 40, 256, 256), (8, 80, 100, 154), (8, 160, 64, 64), (2, 64, 130, 81),
+                                           (4, 8, 33, 5), (4, 16, 64, 200), (2, 32, 700, 1000), (1, 128, 40, 90), (8, 40, 1024, 1024),
+                                           (20, 64, 300, 300), (8, 40, 128, 81)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_flash_attention_row_major_v(heads, d, Nq, Nk, fused):
+    """crg_attention_v: V row-major ([B, Nk, C], transposing LDS read inside the kernel).  `fused`: q / k / v are column slices of
+    one [B, N, 3C] tensor (self-attention, Nq == Nk) or k / v slices of a [B, Nk, 2C] tensor (cross-attention) - the strided views
+    the fused projections hand over - with NaNs in the neighbouring memory that must not leak."""
+    from cremage_amd import ops
+    C = heads * d
+    qq, kk, vv = rnd(2, Nq, C, seed=170), rnd(2, Nk, C, seed=171), rnd(2, Nk, C, seed=172)
+    ref = attn_ref(q(qq, BF), q(kk, BF), q(vv, BF), heads, d ** -0.5)
+    dq, dk, dv = qq.to(_dev()).to(BF), kk.to(_dev()).to(BF), vv.to(_dev()).to(BF)
+    if fused and Nq == Nk:
+        qkv = torch.cat([dq, dk, dv], dim=-1)
+        dq, dk, dv = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    elif fused:
+        kv = torch.cat([dk, dv], dim=-1)
+        dk, dv = kv[..., :C], kv[..., C:]
+    got = ops.attention_rows_v(dq, dk, dv, heads, d ** -0.5).float().cpu()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert torch.isfinite(got).all() and rel < 1e-2, (rel, heads, d, Nq, Nk)
+
+
+def test_flash_attention_row_major_v_spiky_rows():
+    """the online-softmax rescale branch of the row-major-V variant (guide rule 26: force the branch)"""
+    from cremage_amd import ops
+    heads, d, Nq, Nk = 2, 64, 64, 300
+    C = heads * d
+    qq, kk, vv = rnd(1, Nq, C, seed=173), rnd(1, Nk, C, seed=174), rnd(1, Nk, C, seed=175)
+    kk[0, 250] = qq[0, 3] * 4.0
+    kk[0, 70] = qq[0, 9] * 6.0
+    ref = attn_ref(q(qq, BF), q(kk, BF), q(vv, BF), heads, d ** -0.5)
+    got = ops.attention_rows_v(qq.to(_dev()).to(BF), kk.to(_dev()).to(BF), vv.to(_dev()).to(BF), heads, d ** -0.5).float().cpu()
+    assert ((got - ref).norm() / ref.norm()).item() < 1e-2
 
 
 def test_flash_attention_spiky_rows():

@@ -143,6 +143,27 @@ def test_vae_tiny():
     assert max_abs(R.gaussian_sample(mom, noise), g["sample"]) < 1e-4
 
 
+def test_sgm_vae_tiny():
+    """The SDXL first stage (sgm/modules/diffusionmodules/model.py Encoder / Decoder / AttnBlock) against the CPU restatement:
+    same parameter names and shapes as the repo's AutoencoderKL (key-list digest) and the same function."""
+    import hashlib
+    meta, g = load_golden("sgm_vae_tiny")
+    from cremage_amd.ldm_hip.vae import AutoencoderKL
+    dd = meta["dd"]
+    for attn_type in ("vanilla", "vanilla-xformers"):  # sd_xl_base.yaml:82 spells it the second way
+        m = AutoencoderKL(dict(dd, attn_type=attn_type), None, 4)
+        items = sorted(f"{k}:{tuple(v.shape)}" for k, v in m.state_dict().items())
+        assert len(items) == meta["n_keys"] and hashlib.sha1("\n".join(items).encode()).hexdigest() == meta["keys_sha1"]
+    sd = _sd(m, meta)
+    z = synth_input("sgm_vae_tiny.z", (2, 4, 8, 8), meta["seed"])
+    img = synth_input("sgm_vae_tiny.img", (2, 3, 16, 16), meta["seed"], 0.5).clamp(-1, 1)
+    noise = synth_input("sgm_vae_tiny.noise", (2, 4, 8, 8), meta["seed"])
+    assert max_abs(R.autoencoder_decode(sd, dd, z), g["dec"]) < 1e-4
+    mom = R.autoencoder_encode_moments(sd, dd, img)
+    assert max_abs(mom, g["moments"]) < 1e-4
+    assert max_abs(R.gaussian_sample(mom, noise), g["sample"]) < 1e-4
+
+
 def test_schedules():
     meta, g = load_golden("schedules")
     acp = R.alphas_cumprod().float()
