@@ -16,11 +16,11 @@ PREC_BF16, PREC_BF16X3 = 0, 1
 EPI_NONE, EPI_SILU, EPI_GEGLU = 0, 1, 2
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 PACK_LINEAR, PACK_CONV, PACK_GEGLU = 0, 1, 2
-K_SLOTS = 16  # enum crg_kernel_slot
+K_SLOTS = 17  # enum crg_kernel_slot
 SLOT_NAMES = ["gemm_w1", "gemm_w4", "gemm_w5", "gemm_x3", "conv_w1", "conv_w4", "conv_w5", "conv_x3", "splitk_reduce", "attention",
-              "gn_stats", "gn_apply", "layernorm", "elementwise", "conv_small", "softmax"]
+              "gn_stats", "gn_apply", "layernorm", "elementwise", "conv_small", "softmax", "lngemm"]
 SLOT_FAMILY = ["gemm", "gemm", "gemm", "gemm", "conv", "conv", "conv", "conv", "splitk_reduce", "attention", "groupnorm", "groupnorm",
-               "layernorm", "elementwise", "conv_small", "softmax"]
+               "layernorm", "elementwise", "conv_small", "softmax", "gemm"]
 
 c_void_p, c_int, c_int64, c_float, c_size_t = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -38,6 +38,18 @@ class GemmArgs(C.Structure):
         ("a_dtype", c_int), ("y_dtype", c_int), ("prec", c_int),
         ("a_is_weight", c_int),
         ("a_lo", c_void_p),
+    ]
+
+
+class LnGemmArgs(C.Structure):
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_int64),
+        ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float),
+        ("w", c_void_p), ("ldw", c_int64),
+        ("bias", c_void_p),
+        ("y", c_void_p), ("ldy", c_int64),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("epilogue", c_int),
     ]
 
 
@@ -80,6 +92,7 @@ SIGNATURES = {
     "crg_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int]),
     "crg_gemm": (c_int, [c_void_p, c_void_p, C.POINTER(GemmArgs)]),
     "crg_conv2d": (c_int, [c_void_p, c_void_p, C.POINTER(ConvArgs)]),
+    "crg_ln_gemm": (c_int, [c_void_p, c_void_p, C.POINTER(LnGemmArgs)]),
     "crg_pack_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "crg_pack_geglu_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "crg_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,

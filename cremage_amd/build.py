@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libcrg_hip.so")
-SOURCES = ["crg_api.hip", "gemm_conv.hip", "conv_ring.hip", "norms.hip", "attention.hip", "small_ops.hip"]
+SOURCES = ["crg_api.hip", "gemm_conv.hip", "conv_ring.hip", "lngemm.hip", "norms.hip", "attention.hip", "small_ops.hip"]
 HEADERS = [os.path.join(CSRC, "crg_common.h"), os.path.join(CSRC, "gemm_shared.h"), os.path.join(HERE, "..", "include", "crg_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 # attention.hip: without NaN-honouring semantics fmaxf lowers to plain v_max_f32 / v_max3_f32 instead of a canonicalising

@@ -1,0 +1,376 @@
+// LayerNorm fused into the GEMM that consumes it, for short K (the 64x64 level of the SD1.5 UNet: K = 320, M = 32768).
+//
+//   Y[m][n] = epi( LN(X[m][:]) . W[n][:] + bias[n] ),   LN(x) = (x - mean) * rsqrt(var + eps) * gamma + beta
+//
+// replaces nn.LayerNorm + the Linear behind it in BasicTransformerBlock._forward (attention.py:908-912):
+//   norm1 -> to_q | to_k | to_v (one launch over the stacked weights),  norm2 -> to_q,  norm3 -> GEGLU proj (attention.py:88-96).
+// Unfused, the normalised tensor is written to HBM and read back by one to three GEMM launches whose 128 x 160 tiles have only
+// FIVE k-tiles: launch, first DMA and epilogue are most of their 20-110 us.  Here a block keeps its 128 rows RESIDENT in LDS
+// (128 x K bf16 = 80 KB at K = 320, staged once by LDS-DMA through a buffer descriptor, rows past M zero-filled by the range
+// check), normalises them in place (8 lanes per row, two-pass mean / centred variance in fp32, one rounding to bf16 - the
+// arithmetic of layernorm_kernel), and then walks ALL n-tiles of the weight: the weight k-tiles stream through a 4-slot ring
+// without a break at n-tile boundaries (counted vmcnt, one barrier per k-tile), so an n-tile's epilogue (bias, GEGLU, 16-byte
+// stores) runs while the next n-tile's weights are already landing.  X is read once, LN(X) never leaves the chip.
+// 8 waves = 4 (m) x 2 (n), wave tile 32 x 16*WNT; LDS = 16 KB * K/64 + 4 * BN * 128 B (160 KB at K = 320, BN = 160).
+#include "gemm_shared.h"
+
+namespace crg_mm {
+
+struct LnGemmP {
+  const bf16* x; long ldx;
+  const float* gamma; const float* beta; float eps;
+  const bf16* w; long ldw;     // packed [N][K] (GEGLU: value / gate rows interleaved in 16-row groups, crg_pack_weight)
+  const float* bias;           // fp32 [N] (GEGLU: packed like the rows) or null
+  bf16* y; long ldy;
+  int M, N, K, epi;
+  unsigned x_bytes, w_bytes, y_bytes;
+};
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+static __device__ __forceinline__ void ln_dma16(const void* base, unsigned bytes, char* lds, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)lds, 16, voff, soff, 0, 0);
+#endif
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// Epilogue stores through a buffer descriptor: an out-of-range lane (row >= M, column group >= N: offset forced past the end) is
+// DROPPED by the range check, so the store INSTRUCTION COUNT per wave is a compile-time constant whatever the tails are -
+// which is what lets the counted vmcnt waits below leave exactly these stores in flight (vmcnt counts stores on gfx950).
+static __device__ __forceinline__ void ln_store16(void* base, unsigned bytes, int voff, const bf16x8& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
+  u32x4 r;
+  __builtin_memcpy(&r, &v, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(r, rs, voff, 0, 0);
+#endif
+}
+static __device__ __forceinline__ void ln_store8(void* base, unsigned bytes, int voff, const bf16x4& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
+  u32x2 r;
+  __builtin_memcpy(&r, &v, 8);
+  __builtin_amdgcn_raw_buffer_store_b64(r, rs, voff, 0, 0);
+#endif
+}
+
+static __device__ __forceinline__ void ln_wait(int n) {  // wave-uniform s_waitcnt vmcnt(n)
+  switch (n) {
+    case 0: wait_vmcnt<0>(); break;
+    case 2: wait_vmcnt<2>(); break;
+    case 3: wait_vmcnt<3>(); break;
+    case 4: wait_vmcnt<4>(); break;
+    case 5: wait_vmcnt<5>(); break;
+    case 6: wait_vmcnt<6>(); break;
+    case 7: wait_vmcnt<7>(); break;
+    case 8: wait_vmcnt<8>(); break;
+    case 9: wait_vmcnt<9>(); break;
+    default: wait_vmcnt<0>(); break;
+  }
+}
+
+template <int WNT, int KT, bool GEGLU>
+__global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
+  constexpr bool PAIR = !GEGLU;  // plain outputs use the paired column mapping (16-byte stores); GEGLU its own [v16 | g16] packing
+  constexpr int WMT = 2, NW = 8, BMR = 128, WST = 4;
+  constexpr int BN = 32 * WNT;
+  constexpr int WS_BYTES = BN * 128;
+  constexpr int WRG = BN / 8;
+  constexpr int WL = (WRG + NW - 1) / NW;
+  constexpr int A_KT = BMR * 128;           // bytes of one resident k-tile [128 rows][64 k]
+  constexpr int AP = KT * 16 / NW;          // A pieces per wave (KT * 16 pieces of 8 rows x 128 B)
+  static_assert((KT * 16) % NW == 0, "A pieces must divide over the waves");
+  constexpr int OOB = (int)0x80000000;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Ares = smem;                  // [KT][128][128 B], chunk XOR-swizzled by (row & 7)
+  char* const wring = smem + KT * A_KT;     // [WST][BN x 128 B]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BMR;
+  const int rsub = lane >> 3;
+  const int clog = (lane & 7) ^ rsub;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int nW = (WRG - wave + NW - 1) / NW;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int U = tiles_n * KT;               // weight k-tiles this block streams
+  constexpr int NST = GEGLU ? WMT * (WNT / 2) : WMT * (WNT / 2 + (WNT & 1));  // store instructions per wave and n-tile
+
+  // ---- stage the 128 rows (all K) and the first three weight k-tiles ----
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    const int pa = wave + NW * i;           // piece: k-tile pa / 16, row group pa % 16
+    const int kt = pa >> 4, rg = pa & 15;
+    const int row = m0 + rg * 8 + rsub;
+    const int vo = row < p.M ? (int)((long)row * p.ldx * 2) + clog * 16 : OOB;
+    ln_dma16(p.x, p.x_bytes, Ares + kt * A_KT + rg * 1024, vo, kt * 128);
+  }
+  int wvo[WL];
+#pragma unroll
+  for (int q = 0; q < WL; ++q) {
+    const int pos = (wave + NW * q) * 8 + rsub;
+    const int nl = PAIR ? unpair_col<WNT>(pos) : pos;     // column of the tile whose weight row lives at LDS row `pos`
+    wvo[q] = (wave + NW * q) < WRG ? (int)((long)nl * p.ldw * 2) + clog * 16 : OOB;
+  }
+  auto stage_w = [&](int u) {  // weight k-tile u = (n-tile u / KT, k-tile u % KT) into ring slot u & 3
+    const int nt = u / KT, kt = u - nt * KT;
+    char* ws = wring + (u & 3) * WS_BYTES;
+    const int soff = (int)((long)nt * BN * p.ldw * 2) + kt * 128;  // rows past N fall beyond w_bytes: zero-filled
+#pragma unroll
+    for (int q = 0; q < WL; ++q)
+      if ((wave + NW * q) < WRG) ln_dma16(p.w, p.w_bytes, ws + (wave + NW * q) * 1024, wvo[q], soff);
+  };
+  stage_w(0);
+  if (U > 1) stage_w(1);
+  if (U > 2) stage_w(2);
+
+  // ---- LayerNorm of the resident rows, in place: wave w owns rows 16 w .. 16 w + 15, 8 lanes per row ----
+  {
+    const int c = lane & 7, r8 = lane >> 3;
+    f32x4 g0[KT], g1[KT], b0[KT], b1[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const int k = kt * 64 + c * 8;
+      g0[kt] = *reinterpret_cast<const f32x4*>(p.gamma + k);
+      g1[kt] = *reinterpret_cast<const f32x4*>(p.gamma + k + 4);
+      b0[kt] = *reinterpret_cast<const f32x4*>(p.beta + k);
+      b1[kt] = *reinterpret_cast<const f32x4*>(p.beta + k + 4);
+    }
+    // the rows (older than the three weight batches) have landed once at most 3 nW operations of this wave are outstanding;
+    // the gamma / beta loads above are younger still, the compiler waits for them itself at their first use
+    ln_wait(nW * (U < 3 ? U : 3));
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const float inv_k = 1.0f / (float)(KT * 64);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = wave * 16 + it * 8 + r8;
+      bf16x8 v[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) v[kt] = *reinterpret_cast<const bf16x8*>(Ares + kt * A_KT + lds_off(row, c));
+      float s = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)v[kt][e];
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      const float mean = s * inv_k;
+      float qv = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = (float)v[kt][e] - mean;
+          qv += d * d;
+        }
+      qv += __shfl_xor(qv, 1);
+      qv += __shfl_xor(qv, 2);
+      qv += __shfl_xor(qv, 4);
+      const float rstd = rsqrtf(qv * inv_k + p.eps);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float ga = e < 4 ? g0[kt][e] : g1[kt][e - 4], be = e < 4 ? b0[kt][e] : b1[kt][e - 4];
+          o[e] = (bf16)(((float)v[kt][e] - mean) * rstd * ga + be);
+        }
+        *reinterpret_cast<bf16x8*>(Ares + kt * A_KT + lds_off(row, c)) = o;
+      }
+    }
+  }
+  // (the barrier of the first k-tile below orders these LDS writes before every wave's fragment reads)
+
+  f32x4 acc[WNT][WMT];
+#pragma unroll
+  for (int i = 0; i < WNT; ++i)
+#pragma unroll
+    for (int j = 0; j < WMT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wb0 = (wn * (16 * WNT) + frow) * 128 + ((fq ^ (frow & 7)) << 4);
+  int aoff[WMT];
+#pragma unroll
+  for (int j = 0; j < WMT; ++j) aoff[j] = lds_off(wm * 32 + j * 16 + frow, fq);  // second k-step: ^ 64
+
+  // fragment sets: F0 = first 32-wide k-step of the CURRENT k-tile (requested during the previous k-tile, whose barrier already
+  // made this k-tile's weights visible), F1 = its second k-step (requested at the top, consumed after F0's MFMAs)
+  bf16x8 xf0[WMT], wf0[WNT], xf1[WMT], wf1[WNT];
+  auto read_frags = [&](bf16x8 (&xf)[WMT], bf16x8 (&wf)[WNT], int kt, int slot, int ks) {
+    const char* as = Ares + kt * A_KT;
+#pragma unroll
+    for (int j = 0; j < WMT; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(as + (aoff[j] ^ (ks << 6)));
+    const char* wbase = wring + slot * WS_BYTES + (wb0 ^ (ks << 6));
+#pragma unroll
+    for (int i = 0; i < WNT; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wbase + i * 2048);
+  };
+  auto mma = [&](const bf16x8 (&xf)[WMT], const bf16x8 (&wf)[WNT]) {
+#pragma unroll
+    for (int i = 0; i < WNT; ++i)
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+  };
+  {
+    // weight k-tile 0 landed (two batches may stay in flight); this barrier also publishes the normalised rows
+    ln_wait(nW * (U > 2 ? 2 : U - 1));
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(xf0, wf0, 0, 0, 0);
+  }
+  for (int nt = 0; nt < tiles_n; ++nt) {
+    const int n0 = nt * BN;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const int u = nt * KT + kt;
+      // top(u): weight k-tile u + 1 has landed once only the youngest batch (u + 2) is outstanding - everything this k-tile
+      // and the prefetch of the next one read is then visible behind the barrier; stores of the previous epilogue that are
+      // still in the queue only make the wait err on the safe side
+      // ... and the NST stores of the previous n-tile's epilogue, issued between the batches of k-tiles u_e + 3 and u_e + 4
+      // (u_e = that n-tile's last k-tile), are younger than what the first two waits of an n-tile need: they stay in flight too
+      ln_wait((u + 2 < U ? nW : 0) + ((kt < 2 && nt > 0) ? NST : 0));
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      read_frags(xf1, wf1, kt, u & 3, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(xf0, wf0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (u + 3 < U) stage_w(u + 3);  // slot of k-tile u - 1: every wave finished reading it before this k-tile's barrier
+      if (u + 1 < U) read_frags(xf0, wf0, kt + 1 < KT ? kt + 1 : 0, (u + 1) & 3, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(xf1, wf1);
+    }
+    // ---- epilogue of n-tile nt (the ring keeps filling underneath): exactly NST store instructions per wave ----
+    {
+      constexpr int OOBS = (int)0x80000000;
+      const int nb = n0 + wn * (16 * WNT);
+      if constexpr (GEGLU) {
+        // packed columns: [v 16 | g 16] groups; tiles (2u, 2u + 1) of this wave are value / gate (crg_pack_weight CRG_PACK_GEGLU)
+#pragma unroll
+        for (int u2 = 0; u2 < WNT / 2; ++u2) {
+          const int pn = nb + u2 * 32 + fq * 4;       // packed column of the value tile
+          const int jn = nb / 2 + u2 * 16 + fq * 4;   // output column
+          const bool nok = pn + 20 <= p.N;            // the gate group sits 16 packed columns further
+          f32x4 bv = {0.f, 0.f, 0.f, 0.f}, bg = bv;
+          if (p.bias) {
+            const int pc = nok ? pn : 0;
+            bv = *reinterpret_cast<const f32x4*>(p.bias + pc);
+            bg = *reinterpret_cast<const f32x4*>(p.bias + pc + 16);
+          }
+#pragma unroll
+          for (int j = 0; j < WMT; ++j) {
+            const int m = m0 + wm * 32 + j * 16 + frow;
+            const f32x4 v = acc[2 * u2][j] + bv, g = acc[2 * u2 + 1][j] + bg;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[e] * crg_gelu_erf_f(g[e]));
+            ln_store8(p.y, p.y_bytes, (nok && m < p.M) ? (int)(((long)m * p.ldy + jn) * 2) : OOBS, o);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int u2 = 0; u2 < WNT / 2; ++u2) {
+          const int n = nb + 32 * u2 + 8 * fq;        // paired mapping: this lane's 8 consecutive columns of tiles (2u, 2u + 1)
+          const bool nok = n + 8 <= p.N;
+          f32x4 ba = {0.f, 0.f, 0.f, 0.f}, bb = ba;
+          if (p.bias) {
+            const int pc = nok ? n : 0;
+            ba = *reinterpret_cast<const f32x4*>(p.bias + pc);
+            bb = *reinterpret_cast<const f32x4*>(p.bias + pc + 4);
+          }
+#pragma unroll
+          for (int j = 0; j < WMT; ++j) {
+            const int m = m0 + wm * 32 + j * 16 + frow;
+            const f32x4 a4 = acc[2 * u2][j] + ba, b4 = acc[2 * u2 + 1][j] + bb;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o[e] = (bf16)a4[e];
+              o[4 + e] = (bf16)b4[e];
+            }
+            ln_store16(p.y, p.y_bytes, (nok && m < p.M) ? (int)(((long)m * p.ldy + n) * 2) : OOBS, o);
+          }
+        }
+        if constexpr (WNT & 1) {
+          const int n = nb + 16 * (WNT - 1) + 4 * fq;
+          const bool nok = n + 4 <= p.N;
+          f32x4 ba = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias) ba = *reinterpret_cast<const f32x4*>(p.bias + (nok ? n : 0));
+#pragma unroll
+          for (int j = 0; j < WMT; ++j) {
+            const int m = m0 + wm * 32 + j * 16 + frow;
+            const f32x4 a4 = acc[WNT - 1][j] + ba;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)a4[e];
+            ln_store8(p.y, p.y_bytes, (nok && m < p.M) ? (int)(((long)m * p.ldy + n) * 2) : OOBS, o);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WNT; ++i)
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+}  // namespace crg_mm
+
+using namespace crg_mm;
+
+extern "C" int crg_ln_gemm(crg_ctx* ctx, void* stream, const crg_lngemm_args* a) {
+  if (!ctx || !a) return -22;
+  CRG_REQUIRE(ctx, a->M > 0 && a->N > 0 && a->K > 0, "ln_gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
+  CRG_REQUIRE(ctx, a->K == 320, "ln_gemm: the row-resident kernel is built for K = 320 (got %d): use crg_layernorm + crg_gemm", a->K);
+  CRG_REQUIRE(ctx, a->ldx % 8 == 0 && a->ldw % 8 == 0 && a->ldx >= a->K && a->ldw >= a->K, "ln_gemm: ldx=%ld / ldw=%ld must be >= K and keep rows 16-byte aligned",
+              (long)a->ldx, (long)a->ldw);
+  CRG_REQUIRE(ctx, (((uintptr_t)a->x | (uintptr_t)a->w | (uintptr_t)a->y | (uintptr_t)a->gamma | (uintptr_t)a->beta | (uintptr_t)a->bias) & 15) == 0,
+              "ln_gemm: pointers must be 16-byte aligned");
+  CRG_REQUIRE(ctx, a->gamma && a->beta, "ln_gemm: gamma / beta are required");
+  const bool geglu = a->epilogue == CRG_EPI_GEGLU;
+  CRG_REQUIRE(ctx, a->epilogue == CRG_EPI_NONE || geglu, "ln_gemm: epilogue %d unsupported", a->epilogue);
+  if (geglu) CRG_REQUIRE(ctx, a->N % 32 == 0, "ln_gemm: GEGLU needs packed N %% 32 == 0 (got %d)", a->N);
+  const double xb = (double)a->M * a->ldx * 2.0, wb = (double)a->N * a->ldw * 2.0;
+  CRG_REQUIRE(ctx, xb < 2147483648.0 && wb < 2147483648.0, "ln_gemm: operands must be < 2 GiB");
+  LnGemmP p{};
+  p.x = (const bf16*)a->x; p.ldx = a->ldx; p.gamma = a->gamma; p.beta = a->beta; p.eps = a->eps;
+  p.w = (const bf16*)a->w; p.ldw = a->ldw; p.bias = a->bias; p.y = (bf16*)a->y; p.ldy = a->ldy;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.epi = a->epilogue;
+  p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+  const int n_out = geglu ? a->N / 2 : a->N;
+  CRG_REQUIRE(ctx, a->ldy >= n_out, "ln_gemm: ldy=%ld < output width %d", (long)a->ldy, n_out);
+  CRG_REQUIRE(ctx, geglu || (a->N % 8 == 0 && a->ldy % 8 == 0), "ln_gemm: N=%d / ldy=%ld must be multiples of 8 (16-byte output groups)", a->N, (long)a->ldy);
+  CRG_REQUIRE(ctx, !geglu || a->ldy % 4 == 0, "ln_gemm: ldy=%ld must be a multiple of 4", (long)a->ldy);
+  const double yb = (double)a->M * a->ldy * 2.0;
+  CRG_REQUIRE(ctx, yb < 2147483648.0, "ln_gemm: output must be < 2 GiB");
+  p.y_bytes = (unsigned)yb;
+  const bool wide = !geglu && a->N % 160 == 0;
+  hipStream_t st = (hipStream_t)stream;
+  void (*kern)(LnGemmP);
+  int bn;
+  if (geglu) { kern = lngemm_kernel<4, 5, true>; bn = 128; }
+  else if (wide) { kern = lngemm_kernel<5, 5, false>; bn = 160; }
+  else { kern = lngemm_kernel<4, 5, false>; bn = 128; }
+  const size_t lds = (size_t)5 * 128 * 128 + (size_t)4 * bn * 128;
+  static bool attr_set[3] = {};
+  const int ai = geglu ? 0 : (wide ? 1 : 2);
+  if (!attr_set[ai]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return crg_fail(ctx, -5, "ln_gemm: cannot set dynamic LDS: %s", hipGetErrorString(e));
+    attr_set[ai] = true;
+  }
+  const double flops = 2.0 * a->M * (double)a->N * a->K;
+  const double bytes = (double)a->M * a->K * 2 + (double)a->N * a->K * 2 + (double)a->M * n_out * 2;
+  crg_prof_scope ps(ctx, st, CRG_K_LNGEMM, flops, bytes);
+  hipLaunchKernelGGL(kern, dim3((a->M + 127) / 128), dim3(512), lds, st, p);
+  CRG_CHECK_LAUNCH(ctx, "ln_gemm");
+  return 0;
+}

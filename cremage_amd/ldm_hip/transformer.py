@@ -104,8 +104,15 @@ class GEGLU_with_lora(nn.Module):
         self.proj = Linear(dim_in, dim_out * 2)
         _lora_lists(self, "proj", dim_in, dim_out * 2, self.lora_ranks)
 
-    def forward(self, x):
-        return ops.linear(x, _eff(self, self.proj.weight, "proj"), self.proj.bias, act="geglu")
+    def forward(self, x, ln: Optional[nn.LayerNorm] = None):
+        """`ln`: the LayerNorm in front of this projection, to be applied to x first - fused into the GEMM launch where the
+        row-resident kernel takes the shape (ops.ln_linear_ok), as a separate pass otherwise."""
+        w = _eff(self, self.proj.weight, "proj")
+        if ln is not None:
+            if ops.ln_linear_ok(x, w):
+                return ops.ln_linear(x, ln.weight, ln.bias, ln.eps, w, self.proj.bias, act="geglu")
+            x = ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
+        return ops.linear(x, w, self.proj.bias, act="geglu")
 
 
 class FeedForward(nn.Module):
@@ -126,8 +133,8 @@ class FeedForward(nn.Module):
                                   nn.Dropout(dropout), Linear(inner_dim, dim_out)])
         _lora_lists(self, "net_2", inner_dim, dim_out, self.lora_ranks)
 
-    def forward(self, x, residual=None):
-        h = self.net[0](x)
+    def forward(self, x, residual=None, ln: Optional[nn.LayerNorm] = None):
+        h = self.net[0](x, ln=ln)
         return ops.linear(h, _eff(self, self.net[2].weight, "net_2"), self.net[2].bias, residual=residual)
 
 
@@ -199,10 +206,20 @@ class CrossAttention(nn.Module):
         self._kv = (context, context._version, wkeys, out)
         return out
 
-    def forward(self, x, context=None, mask=None, residual=None):
+    def forward(self, x, context=None, mask=None, residual=None, ln: Optional[nn.LayerNorm] = None):
+        """`ln` (not in the reference's signature; passed by BasicTransformerBlock): the LayerNorm in front of this attention.
+        Its application is this module's job then - fused into the projection launch where ops.ln_linear_ok allows."""
         if exists(mask):
             raise NotImplementedError("attention masks are never passed on the SD path (attention.py:648-652)")
         fused = self._fused(x.dtype)
+
+        def project(w):  # LayerNorm (if any) + the projection of x, one launch when the shape allows
+            nonlocal x, ln
+            if ln is not None:
+                if ops.ln_linear_ok(x, w):
+                    return ops.ln_linear(x, ln.weight, ln.bias, ln.eps, w)
+                x, ln = ops.layer_norm(x, ln.weight, ln.bias, ln.eps), None
+            return ops.linear(x, w)
         if context is None:
             wq, wk, wv = _eff(self, self.to_q.weight, "q"), _eff(self, self.to_k.weight, "k"), _eff(self, self.to_v.weight, "v")
             c = wq.shape[0]
@@ -210,15 +227,17 @@ class CrossAttention(nn.Module):
                 raise NotImplementedError("ipa_num_tokens > 0 needs a context (attention.py:623-627)")
             if fused:
                 # self-attention: the three projections share their input -> ONE GEMM, q / k / v are column slices of its output
-                qkv = ops.linear(x, self._stack(wq, wk, wv))
+                qkv = project(self._stack(wq, wk, wv))
                 out = ops.attention_rows_v(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads, self.scale)
                 return ops.linear(out, _eff(self, self.to_out[0].weight, "out"), self.to_out[0].bias, residual=residual)
+            if ln is not None:
+                x, ln = ops.layer_norm(x, ln.weight, ln.bias, ln.eps), None
             qk = ops.linear(x, self._stack(wq, wk))
             q, k = qk[..., :c], qk[..., c:]
             vt = ops.linear_transposed(x, wv)
             nk, ipa = x.shape[1], None
         else:
-            q = ops.linear(x, _eff(self, self.to_q.weight, "q"))
+            q = project(_eff(self, self.to_q.weight, "q"))
             k, vt, nk, ipa = self._project_kv(context, x.dtype)
         att = (lambda kk, vv, n: ops.attention_rows_v(q, kk, vv, self.heads, self.scale)) if fused else \
               (lambda kk, vv, n: ops.attention(q, kk, vv, self.heads, n, self.scale))
@@ -268,9 +287,11 @@ class BasicTransformerBlock(nn.Module):
         return self._forward(x, context)
 
     def _forward(self, x, context=None):
-        x = self.attn1(self._ln(self.norm1, x), context=context if self.disable_self_attn else None, residual=x)
-        x = self.attn2(self._ln(self.norm2, x), context=context, residual=x)
-        x = self.ff(self._ln(self.norm3, x), residual=x)
+        # x = attn1(norm1(x)) + x; x = attn2(norm2(x), ctx) + x; x = ff(norm3(x)) + x (attention.py:908-912).  The LayerNorms are
+        # handed to the consumers, which fuse them into their first GEMM launch where the kernel takes the shape
+        x = self.attn1(x, context=context if self.disable_self_attn else None, residual=x, ln=self.norm1)
+        x = self.attn2(x, context=context, residual=x, ln=self.norm2)
+        x = self.ff(x, residual=x, ln=self.norm3)
         return x
 
 

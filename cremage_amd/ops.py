@@ -326,6 +326,39 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return y
 
 
+def ln_linear_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Shapes crg_ln_gemm takes (the row-resident LayerNorm + GEMM kernel): bf16 tokens of width 320."""
+    return x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 320 and weight[0].numel() == 320 and weight.shape[0] % 16 == 0
+
+
+def ln_linear(x: torch.Tensor, ln_weight, ln_bias, eps: float, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+              act: Optional[str] = None) -> torch.Tensor:
+    """y = act(LayerNorm(x) @ weight^T + bias) in ONE launch (crg_ln_gemm): nn.LayerNorm + the Linear behind it.
+    act: None | 'geglu'.  Falls back to nothing - callers test ln_linear_ok() and otherwise run layer_norm + linear."""
+    _need_cuda(x, ln_weight, ln_bias, weight, bias)
+    if not ln_linear_ok(x, weight):
+        raise L.CrgError("ln_linear: bf16 tokens of width 320 expected (use layer_norm + linear)")
+    x = x.contiguous()
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = weight.shape[0]
+    geglu = act == "geglu"
+    if act not in (None, "geglu"):
+        raise L.CrgError(f"ln_linear: activation {act!r} unsupported")
+    hi, _ = packed_weight(weight, L.PACK_GEGLU if geglu else L.PACK_LINEAR, False)
+    n_out = N // 2 if geglu else N
+    y = torch.empty(x.shape[:-1] + (n_out,), dtype=x.dtype, device=x.device)
+    b = None
+    if bias is not None:
+        b = packed_geglu_bias(bias) if geglu else f32_vec(bias)
+    a = L.LnGemmArgs(x=x.data_ptr(), ldx=K, gamma=_p(f32_vec(ln_weight)).value, beta=_p(f32_vec(ln_bias)).value, eps=float(eps),
+                     w=hi.data_ptr(), ldw=K, bias=_p(b).value, y=y.data_ptr(), ldy=n_out, M=M, N=N, K=K,
+                     epilogue=L.EPI_GEGLU if geglu else L.EPI_NONE)
+    h = _h(x)
+    L.check(L.load().crg_ln_gemm(h, _st(), C.byref(a)), h, "crg_ln_gemm")
+    return y
+
+
 def linear_transposed(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[b] = weight @ x[b]^T (+ bias per row): [B, T, K] tokens -> [B, N, ld] with ld = roundup(T, 8).
     Emits the V projection already transposed ([channel][key]) for crg_attention; pad columns are
@@ -349,9 +382,9 @@ def linear_transposed(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
               residual=None, ldr=0, r_bstride=0, y=y.data_ptr(), ldy=ld, y_bstride=N * ld, M=N, N=T, K=K, batch=B,
               epilogue=L.EPI_NONE, a_dtype=L.BF16, y_dtype=L.BF16, prec=L.PREC_BF16, a_is_weight=1, a_lo=None)
     else:
-        # fp32 activations cannot sit on the pre-split W side: split them once on the fly
-        xh = x.to(torch.bfloat16)
-        xl = (x - xh.float()).to(torch.bfloat16)
+        # fp32 activations cannot sit on the pre-split W side: split them once on the fly (crg_split_bf16, no torch arithmetic)
+        xh, xl = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device), torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        L.check(L.load().crg_split_bf16(h, _st(), _p(x), _p(xh), _p(xl), x.numel()), h, "crg_split_bf16")
         _gemm(h, a=hi.data_ptr(), lda=K, a_bstride=0, a_lo=lo.data_ptr(), w=xh.data_ptr(), w_lo=xl.data_ptr(), ldw=K,
               w_bstride=T * K, bias=b.data_ptr() if b is not None else None,
               bias_mode=L.BIAS_ROW if b is not None else L.BIAS_NONE, residual=None, ldr=0, r_bstride=0, y=y.data_ptr(), ldy=ld,
@@ -466,34 +499,46 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, n_
                                        L.BF16), h, "crg_attention")
         return o
     q, k = q.contiguous(), k.contiguous()
-    # Unfused path: S = QK^T (fp32) -> row softmax -> PV, all on the GEMM kernels.  Serves the fp32-class
-    # (BF16X3) configuration and head dims beyond the flash kernel (the VAE's single-head C=512
-    # AttnBlock, model.py:185-209).
+    # Unfused path: S = QK^T (fp32) -> row softmax -> PV, all on the GEMM kernels.  Serves the fp32-class (BF16X3)
+    # configuration and head dims beyond the flash kernel (the VAE's single-head C=512 AttnBlock, model.py:185-209).
+    # The score matrix is never held whole: queries are processed in chunks sized so that the fp32 score buffer stays
+    # <= ~256 MB (the reference's original path materialises all of it - 1 GiB per image at 1024x1024, attention.py:389-429),
+    # hi / lo planes come from crg_split_bf16, and no PyTorch arithmetic runs.
     split = q.dtype == torch.float32
     o = torch.empty_like(q)
     kp = (n_keys + 7) // 8 * 8
-    s = torch.empty((heads, Nq, kp), dtype=torch.float32, device=q.device)
+    prec = L.PREC_BF16X3 if split else L.PREC_BF16
+
+    def planes(t):
+        if not split:
+            return t, None
+        th, tl = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device), torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+        L.check(L.load().crg_split_bf16(h, _st(), _p(t), _p(th), _p(tl), t.numel()), h, "crg_split_bf16")
+        return th, tl
+    kh, kl = planes(k)            # [B, Nk, C]
+    vh, vl = planes(vt)           # [B, C, ld]
+    qc = max(8, min(Nq, (256 << 20) // (4 * heads * kp) // 8 * 8))  # queries per chunk
+    s = torch.empty((heads, min(qc, Nq), kp), dtype=torch.float32, device=q.device)
     if kp != n_keys:
         s[:, :, n_keys:].zero_()
     for b in range(B):
-        kb, vb = k[b], vt[b]
-        if split:
-            kh = kb.to(torch.bfloat16)
-            kl = (kb - kh.float()).to(torch.bfloat16)
-            vh = vb.to(torch.bfloat16)
-            vl = (vb - vh.float()).to(torch.bfloat16)
-        else:
-            kh, kl, vh, vl = kb, None, vb, None
-        prec = L.PREC_BF16X3 if split else L.PREC_BF16
-        _gemm(h, a=q[b].data_ptr(), lda=Cc, a_bstride=Dh, w=kh.data_ptr(), w_lo=kl.data_ptr() if split else None, ldw=Cc,
-              w_bstride=Dh, bias=None, bias_mode=L.BIAS_NONE, residual=None, ldr=0, r_bstride=0, y=s.data_ptr(), ldy=kp,
-              y_bstride=Nq * kp, M=Nq, N=n_keys, K=Dh, batch=heads, epilogue=L.EPI_NONE, a_dtype=_act_dt(q), y_dtype=L.F32,
-              prec=prec, a_is_weight=0, a_lo=None)
-        softmax_rows_(s, n_keys, scale)
-        _gemm(h, a=s.data_ptr(), lda=kp, a_bstride=Nq * kp, w=vh.data_ptr(), w_lo=vl.data_ptr() if split else None, ldw=ld,
-              w_bstride=Dh * ld, bias=None, bias_mode=L.BIAS_NONE, residual=None, ldr=0, r_bstride=0, y=o[b].data_ptr(), ldy=Cc,
-              y_bstride=Dh, M=Nq, N=Dh, K=kp, batch=heads, epilogue=L.EPI_NONE, a_dtype=L.F32, y_dtype=_act_dt(q), prec=prec,
-              a_is_weight=0, a_lo=None)
+        for q0 in range(0, Nq, qc):
+            nq = min(qc, Nq - q0)
+            sv = s[:, :nq]
+            ld_s = s.shape[1] * kp  # head stride of the score buffer
+            _gemm(h, a=q[b, q0:].data_ptr(), lda=Cc, a_bstride=Dh, w=kh[b].data_ptr(), w_lo=kl[b].data_ptr() if split else None, ldw=Cc,
+                  w_bstride=Dh, bias=None, bias_mode=L.BIAS_NONE, residual=None, ldr=0, r_bstride=0, y=sv.data_ptr(), ldy=kp,
+                  y_bstride=ld_s, M=nq, N=n_keys, K=Dh, batch=heads, epilogue=L.EPI_NONE, a_dtype=_act_dt(q), y_dtype=L.F32,
+                  prec=prec, a_is_weight=0, a_lo=None)
+            if nq == s.shape[1]:
+                softmax_rows_(s, n_keys, scale)
+            else:  # last, shorter chunk: the rows of one head are contiguous [nq, kp]
+                for hd in range(heads):
+                    softmax_rows_(s[hd, :nq], n_keys, scale)
+            _gemm(h, a=sv.data_ptr(), lda=kp, a_bstride=ld_s, w=vh[b].data_ptr(), w_lo=vl[b].data_ptr() if split else None, ldw=ld,
+                  w_bstride=Dh * ld, bias=None, bias_mode=L.BIAS_NONE, residual=None, ldr=0, r_bstride=0, y=o[b, q0:].data_ptr(), ldy=Cc,
+                  y_bstride=Dh, M=nq, N=Dh, K=kp, batch=heads, epilogue=L.EPI_NONE, a_dtype=L.F32, y_dtype=_act_dt(q), prec=prec,
+                  a_is_weight=0, a_lo=None)
     return o
 
 

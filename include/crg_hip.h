@@ -65,10 +65,12 @@ int crg_ctx_reserve(crg_ctx* ctx, size_t bytes);
 enum crg_kernel_slot {
   CRG_K_GEMM_W1 = 0, CRG_K_GEMM_W4 = 1, CRG_K_GEMM_W5 = 2, /* gemm_glds_kernel<WNT, *, CONV=false>  bf16 LDS-DMA GEMM      */
   CRG_K_GEMM_X3 = 3,                                        /* gemm_kernel<*, *, *, *, false>        fp32 / split-bf16 GEMM */
-  CRG_K_CONV_W1 = 4, CRG_K_CONV_W4 = 5, CRG_K_CONV_W5 = 6, /* conv3_rowhalo_kernel<WNT> / gemm_glds_kernel<WNT, *, CONV=true>  bf16 implicit-GEMM conv */
+  CRG_K_CONV_W1 = 4, CRG_K_CONV_W4 = 5, CRG_K_CONV_W5 = 6, /* conv3_ring_kernel<WNT> / conv3_rowhalo_kernel<WNT> / gemm_glds_kernel<WNT, *, CONV=true>  bf16 implicit-GEMM conv */
   CRG_K_CONV_X3 = 7,                                        /* gemm_kernel<*, *, *, *, true>         fp32-class conv (VAE)  */
   CRG_K_SPLITK = 8, CRG_K_ATTN = 9, CRG_K_GN_STATS = 10, CRG_K_GN_APPLY = 11, CRG_K_LAYERNORM = 12,
-  CRG_K_ELEMENTWISE = 13, CRG_K_CONV_SMALL = 14, CRG_K_SOFTMAX = 15, CRG_K_SLOTS = 16
+  CRG_K_ELEMENTWISE = 13, CRG_K_CONV_SMALL = 14, CRG_K_SOFTMAX = 15,
+  CRG_K_LNGEMM = 16,                                        /* lngemm_kernel<WNT, KT, PAIR>          LayerNorm fused into the consuming GEMM */
+  CRG_K_SLOTS = 17
 };
 typedef struct {
   double ms[CRG_K_SLOTS];     /* summed device time per kernel slot          */
@@ -106,6 +108,26 @@ int crg_split_bf16(crg_ctx* ctx, void* stream, const void* x, void* hi, void* lo
  * x,y: [rows][dim] of `dtype`; gamma,beta fp32 [dim]. */
 int crg_layernorm(crg_ctx* ctx, void* stream, const void* x, const float* gamma, const float* beta, void* y,
                   int64_t rows, int dim, float eps, int dtype);
+
+/* ---- LayerNorm fused into the GEMM that consumes it: Y = epi(LN(X) (MxK) * W^T (NxK) + bias) --------------------
+ * Replaces nn.LayerNorm + the Linear(s) behind it in BasicTransformerBlock._forward (attention.py:908-912):
+ * norm1 -> to_q | to_k | to_v (:614,629,636; one launch over the row-stacked weights), norm2 -> to_q, norm3 -> the GEGLU
+ * projection (:88-96).  A block keeps its 128 rows resident in LDS, normalises them in place and walks every n-tile of W:
+ * X is read once and LN(X) never reaches HBM.  bf16 in / out, fp32 statistics (two-pass, as crg_layernorm).
+ *   x: bf16 [M][ldx];  gamma, beta: fp32 [K];  w: bf16 [N][ldw] (crg_pack_weight; GEGLU: CRG_PACK_GEGLU);  bias: fp32 [N]
+ *   (GEGLU: crg_pack_geglu_bias) or NULL;  y: bf16 [M][ldy];  epilogue: CRG_EPI_NONE | CRG_EPI_GEGLU (then y is [M][N/2]).
+ * Built for K == 320 (the 64x64 level of SD1.5, where these GEMMs have five k-tiles and are launch / latency bound);
+ * other K return an error: the caller uses crg_layernorm + crg_gemm. */
+typedef struct {
+  const void* x; int64_t ldx;
+  const float* gamma; const float* beta; float eps;
+  const void* w; int64_t ldw;
+  const float* bias;
+  void* y; int64_t ldy;
+  int M, N, K;
+  int epilogue;
+} crg_lngemm_args;
+int crg_ln_gemm(crg_ctx* ctx, void* stream, const crg_lngemm_args* args);
 
 /* ---- GEMM: Y[b] = epi(A[b] (MxK) * W[b]^T (NxK) + bias) + residual ------------------------
  * Replaces F.linear / 1x1 nn.Conv2d call sites: to_q/to_k/to_v (attention.py:614,629,636),

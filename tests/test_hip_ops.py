@@ -96,6 +96,35 @@ def test_geglu(dtype, M, C):
     check(got, ref, dtype, "geglu")
 
 
+@pytest.mark.parametrize("M,N,act,bias", [(300, 960, None, False), (1024, 320, None, False), (4096, 2560, "geglu", True), (128, 336, None, True),
+                                          (77, 400, None, True), (2, 640, "geglu", True), (32768, 960, None, False)])
+def test_ln_linear(M, N, act, bias):
+    """crg_ln_gemm (LayerNorm fused into the consuming GEMM, K = 320; lngemm.hip) against LayerNorm -> bf16 rounding -> Linear:
+    row tails (M % 128 != 0), 160- and 128-wide tiles, the paired and the plain column mapping, bias, GEGLU, and bitwise
+    agreement of the normalised operand with the stand-alone crg_layernorm (same two-pass arithmetic)."""
+    from cremage_amd import ops
+    K = 320
+    x = rnd(M, K, seed=140, scale=2.0) + 0.7
+    g, be = 1 + 0.2 * rnd(K, seed=141), 0.3 * rnd(K, seed=142)
+    w, b = rnd(N, K, seed=143, scale=K ** -0.5), (rnd(N, seed=144, scale=0.2) if bias else None)
+    xq = q(x, BF)
+    ln = q(F.layer_norm(xq, (K,), g, be, 1e-5), BF)                 # the MFMA operand is LN(x) rounded to bf16 once
+    o = F.linear(ln, q(w, BF), b)
+    if act == "geglu":
+        a_, g_ = o.chunk(2, dim=-1)
+        ref = a_ * F.gelu(g_)
+    else:
+        ref = o
+    dx, dw = x.to(_dev()).to(BF), w.to(_dev()).to(BF)
+    assert ops.ln_linear_ok(dx, dw)
+    got = ops.ln_linear(dx, g.to(_dev()), be.to(_dev()), 1e-5, dw, b.to(_dev()) if bias else None, act=act)
+    check(got, ref, BF, f"ln_linear {M}x{N} {act}")
+    two = ops.linear(ops.layer_norm(dx, g.to(_dev()), be.to(_dev()), 1e-5), dw, b.to(_dev()) if bias else None, act=act)
+    d = (got.float() - two.float()).abs().max().item()
+    # same LN arithmetic up to the order of the fp32 row sums: a few elements of LN(x) may round to the neighbouring bf16
+    assert d <= 2 ** -6 * max(1.0, two.float().abs().max().item()), d
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("T", [77, 154, 64, 1])
 def test_linear_transposed(dtype, T):

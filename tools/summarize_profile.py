@@ -50,6 +50,11 @@ def slot_of(name):
         re.search(r"conv3_rowhalo_kernel<(\d), (?:bool _Accum, bool, E|[\w ]+, (?:true|false)), (\d+),", name)
     if m:
         return "conv_x3" if m.group(2) == "2" else "conv_w" + m.group(1)
+    m = re.search(r"conv3_ring_kernelILi(\d)E", name) or re.search(r"conv3_ring_kernel<(\d),", name)
+    if m:
+        return "conv_w" + m.group(1)
+    if "lngemm_kernel" in name:
+        return "lngemm"
     if "gemm_kernel" in name:
         return "conv_x3" if (("Lb1E" in name) or re.search(r", true[,>]", name)) else "gemm_x3"
     for pat, slot in (("splitk_reduce", "splitk_reduce"), ("attn_kernel", "attention"), ("gn_stats", "gn_stats"), ("gn_apply", "gn_apply"), ("gn_small", "gn_apply"),
