@@ -29,6 +29,11 @@ from .. import ops
 from .nn import Conv2d, Linear, Normalize, zero_module
 
 
+import os
+
+_SELF_QKV = os.environ.get("CRG_SELF_QKV", "1") != "0"  # dev knob: 0 = self-attention as fused Q|K GEMM + transposed-V GEMM (round-1 form)
+
+
 def exists(v):
     return v is not None
 
@@ -225,7 +230,7 @@ class CrossAttention(nn.Module):
             c = wq.shape[0]
             if self.ipa_num_tokens > 0:
                 raise NotImplementedError("ipa_num_tokens > 0 needs a context (attention.py:623-627)")
-            if fused:
+            if fused and _SELF_QKV:
                 # self-attention: the three projections share their input -> ONE GEMM, q / k / v are column slices of its output
                 qkv = project(self._stack(wq, wk, wv))
                 out = ops.attention_rows_v(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads, self.scale)
@@ -236,6 +241,8 @@ class CrossAttention(nn.Module):
             q, k = qk[..., :c], qk[..., c:]
             vt = ops.linear_transposed(x, wv)
             nk, ipa = x.shape[1], None
+            out = ops.attention(q, k, vt, self.heads, nk, self.scale)
+            return ops.linear(out, _eff(self, self.to_out[0].weight, "out"), self.to_out[0].bias, residual=residual)
         else:
             q = project(_eff(self, self.to_q.weight, "q"))
             k, vt, nk, ipa = self._project_kv(context, x.dtype)

@@ -6,11 +6,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cremage_amd import ops
 dev = "cuda:0"
 torch.manual_seed(0)
+QS = float(os.environ.get("QSCALE", "1.0"))  # < 1: flat softmax (the running max rarely moves), like the synthetic-weight model
 for (B, N, M, heads, d) in [(8, 4096, 4096, 8, 40), (8, 1024, 1024, 8, 80), (8, 256, 256, 8, 160), (8, 4096, 77, 8, 40), (4, 4096, 4096, 10, 64),
                             (4, 1024, 1024, 20, 64)]:
     C = heads * d
-    q = torch.randn(B, N, C, device=dev).to(torch.bfloat16)
-    k = torch.randn(B, M, C, device=dev).to(torch.bfloat16)
+    q = (QS * torch.randn(B, N, C, device=dev)).to(torch.bfloat16)
+    k = (QS * torch.randn(B, M, C, device=dev)).to(torch.bfloat16)
     v = torch.randn(B, M, C, device=dev).to(torch.bfloat16)
     vt = torch.nn.functional.pad(v.transpose(1, 2), (0, (-M) % 8)).contiguous()
     qkv = torch.cat([q, k, v], -1) if N == M else None
