@@ -50,6 +50,7 @@ class LnGemmArgs(C.Structure):
         ("y", c_void_p), ("ldy", c_int64),
         ("M", c_int), ("N", c_int), ("K", c_int),
         ("epilogue", c_int),
+        ("vt", c_void_p), ("vt_n0", c_int), ("vt_tokens", c_int), ("vt_ld", c_int64),
     ]
 
 

@@ -24,6 +24,10 @@ struct LnGemmP {
   bf16* y; long ldy;
   int M, N, K, epi;
   unsigned x_bytes, w_bytes, y_bytes;
+  // columns n >= vt_n0 (a multiple of the tile width; vt == null: none) are written TRANSPOSED: vt[(m / vt_T) * Cv + n - vt_n0][m % vt_T],
+  // row length vt_ld - the V^T operand of crg_attention, so that to_q | to_k | to_v stay one launch and the flash kernel keeps
+  // its conflict-free transposed-V staging (the row-major-V variant measured 10-20 % slower on the 4096-token self-attention)
+  bf16* vt; int vt_n0, vt_T; long vt_ld; unsigned vt_bytes;
 };
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -57,9 +61,19 @@ static __device__ __forceinline__ void ln_store8(void* base, unsigned bytes, int
 #endif
 }
 
-static __device__ __forceinline__ void ln_wait(int n) {  // wave-uniform s_waitcnt vmcnt(n)
+static __device__ __forceinline__ void ln_store2(void* base, unsigned bytes, int voff, bf16 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
+  short r;
+  __builtin_memcpy(&r, &v, 2);
+  __builtin_amdgcn_raw_buffer_store_b16(r, rs, voff, 0, 0);
+#endif
+}
+
+static __device__ __forceinline__ void ln_wait(int n) {  // wave-uniform s_waitcnt vmcnt(n); n outside the table waits for everything
   switch (n) {
     case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<1>(); break;
     case 2: wait_vmcnt<2>(); break;
     case 3: wait_vmcnt<3>(); break;
     case 4: wait_vmcnt<4>(); break;
@@ -68,6 +82,44 @@ static __device__ __forceinline__ void ln_wait(int n) {  // wave-uniform s_waitc
     case 7: wait_vmcnt<7>(); break;
     case 8: wait_vmcnt<8>(); break;
     case 9: wait_vmcnt<9>(); break;
+    case 10: wait_vmcnt<10>(); break;
+    case 11: wait_vmcnt<11>(); break;
+    case 12: wait_vmcnt<12>(); break;
+    case 13: wait_vmcnt<13>(); break;
+    case 14: wait_vmcnt<14>(); break;
+    case 15: wait_vmcnt<15>(); break;
+    case 16: wait_vmcnt<16>(); break;
+    case 17: wait_vmcnt<17>(); break;
+    case 18: wait_vmcnt<18>(); break;
+    case 19: wait_vmcnt<19>(); break;
+    case 20: wait_vmcnt<20>(); break;
+    case 21: wait_vmcnt<21>(); break;
+    case 22: wait_vmcnt<22>(); break;
+    case 23: wait_vmcnt<23>(); break;
+    case 24: wait_vmcnt<24>(); break;
+    case 25: wait_vmcnt<25>(); break;
+    case 26: wait_vmcnt<26>(); break;
+    case 27: wait_vmcnt<27>(); break;
+    case 28: wait_vmcnt<28>(); break;
+    case 29: wait_vmcnt<29>(); break;
+    case 30: wait_vmcnt<30>(); break;
+    case 31: wait_vmcnt<31>(); break;
+    case 32: wait_vmcnt<32>(); break;
+    case 33: wait_vmcnt<33>(); break;
+    case 34: wait_vmcnt<34>(); break;
+    case 35: wait_vmcnt<35>(); break;
+    case 36: wait_vmcnt<36>(); break;
+    case 37: wait_vmcnt<37>(); break;
+    case 38: wait_vmcnt<38>(); break;
+    case 39: wait_vmcnt<39>(); break;
+    case 40: wait_vmcnt<40>(); break;
+    case 41: wait_vmcnt<41>(); break;
+    case 42: wait_vmcnt<42>(); break;
+    case 43: wait_vmcnt<43>(); break;
+    case 44: wait_vmcnt<44>(); break;
+    case 45: wait_vmcnt<45>(); break;
+    case 46: wait_vmcnt<46>(); break;
+    case 47: wait_vmcnt<47>(); break;
     default: wait_vmcnt<0>(); break;
   }
 }
@@ -100,6 +152,7 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
   const int tiles_n = (p.N + BN - 1) / BN;
   const int U = tiles_n * KT;               // weight k-tiles this block streams
   constexpr int NST = GEGLU ? WMT * (WNT / 2) : WMT * (WNT / 2 + (WNT & 1));  // store instructions per wave and n-tile
+  constexpr int NSTT = WMT * (8 * (WNT / 2) + 4 * (WNT & 1));                // ... of an n-tile that is written transposed
 
   // ---- stage the 128 rows (all K) and the first three weight k-tiles ----
 #pragma unroll
@@ -234,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
       // still in the queue only make the wait err on the safe side
       // ... and the NST stores of the previous n-tile's epilogue, issued between the batches of k-tiles u_e + 3 and u_e + 4
       // (u_e = that n-tile's last k-tile), are younger than what the first two waits of an n-tile need: they stay in flight too
-      ln_wait((u + 2 < U ? nW : 0) + ((kt < 2 && nt > 0) ? NST : 0));
+      ln_wait((u + 2 < U ? nW : 0) + ((kt < 2 && nt > 0) ? ((!GEGLU && p.vt && (nt - 1) * BN >= p.vt_n0) ? NSTT : NST) : 0));
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -272,6 +325,35 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[e] * crg_gelu_erf_f(g[e]));
             ln_store8(p.y, p.y_bytes, (nok && m < p.M) ? (int)(((long)m * p.ldy + jn) * 2) : OOBS, o);
+          }
+        }
+      } else if (p.vt && n0 >= p.vt_n0) {
+        // transposed n-tile (V^T): lane = one token x 8 (4) consecutive channels -> one 2-byte store per channel; the 16 lanes of
+        // a quarter wave hold 16 consecutive tokens, i.e. 32 contiguous bytes of a V^T row per store instruction and quarter
+        const int Cv = p.N - p.vt_n0;
+#pragma unroll
+        for (int j = 0; j < WMT; ++j) {
+          const int m = m0 + wm * 32 + j * 16 + frow;
+          const int bs = m / p.vt_T, tk = m - bs * p.vt_T;
+          const long row0 = (long)bs * Cv - p.vt_n0;
+#pragma unroll
+          for (int u2 = 0; u2 < WNT / 2; ++u2) {
+            const int n = nb + 32 * u2 + 8 * fq;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float v = e < 4 ? acc[2 * u2][j][e] : acc[2 * u2 + 1][j][e - 4];
+              const float bsv = p.bias ? p.bias[n + e < p.N ? n + e : 0] : 0.f;
+              ln_store2(p.vt, p.vt_bytes, (n + e < p.N && m < p.M) ? (int)(((row0 + n + e) * p.vt_ld + tk) * 2) : OOBS, (bf16)(v + bsv));
+            }
+          }
+          if constexpr (WNT & 1) {
+            const int n = nb + 16 * (WNT - 1) + 4 * fq;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float bsv = p.bias ? p.bias[n + e < p.N ? n + e : 0] : 0.f;
+              ln_store2(p.vt, p.vt_bytes, (n + e < p.N && m < p.M) ? (int)(((row0 + n + e) * p.vt_ld + tk) * 2) : OOBS,
+                        (bf16)(acc[WNT - 1][j][e] + bsv));
+            }
           }
         }
       } else {
@@ -345,7 +427,17 @@ extern "C" int crg_ln_gemm(crg_ctx* ctx, void* stream, const crg_lngemm_args* a)
   p.w = (const bf16*)a->w; p.ldw = a->ldw; p.bias = a->bias; p.y = (bf16*)a->y; p.ldy = a->ldy;
   p.M = a->M; p.N = a->N; p.K = a->K; p.epi = a->epilogue;
   p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
-  const int n_out = geglu ? a->N / 2 : a->N;
+  if (a->vt) {
+    CRG_REQUIRE(ctx, !geglu, "ln_gemm: a transposed column range and GEGLU do not combine");
+    CRG_REQUIRE(ctx, a->vt_n0 > 0 && a->vt_n0 < a->N && a->vt_tokens > 0 && a->M % a->vt_tokens == 0 && a->vt_ld >= a->vt_tokens,
+                "ln_gemm: transposed range n0=%d tokens=%d ld=%ld inconsistent with M=%d N=%d", a->vt_n0, a->vt_tokens, (long)a->vt_ld, a->M, a->N);
+    const int bn_ = a->N % 160 == 0 ? 160 : 128;
+    CRG_REQUIRE(ctx, a->vt_n0 % bn_ == 0, "ln_gemm: the transposed range must start on a %d-column tile (got %d)", bn_, a->vt_n0);
+    const double vb = (double)(a->M / a->vt_tokens) * (a->N - a->vt_n0) * a->vt_ld * 2.0;
+    CRG_REQUIRE(ctx, vb < 2147483648.0 && ((uintptr_t)a->vt & 1) == 0, "ln_gemm: V^T output must be < 2 GiB");
+    p.vt = (bf16*)a->vt; p.vt_n0 = a->vt_n0; p.vt_T = a->vt_tokens; p.vt_ld = a->vt_ld; p.vt_bytes = (unsigned)vb;
+  }
+  const int n_out = geglu ? a->N / 2 : (a->vt ? a->vt_n0 : a->N);
   CRG_REQUIRE(ctx, a->ldy >= n_out, "ln_gemm: ldy=%ld < output width %d", (long)a->ldy, n_out);
   CRG_REQUIRE(ctx, geglu || (a->N % 8 == 0 && a->ldy % 8 == 0), "ln_gemm: N=%d / ldy=%ld must be multiples of 8 (16-byte output groups)", a->N, (long)a->ldy);
   CRG_REQUIRE(ctx, !geglu || a->ldy % 4 == 0, "ln_gemm: ldy=%ld must be a multiple of 4", (long)a->ldy);

@@ -230,9 +230,16 @@ class CrossAttention(nn.Module):
             c = wq.shape[0]
             if self.ipa_num_tokens > 0:
                 raise NotImplementedError("ipa_num_tokens > 0 needs a context (attention.py:623-627)")
+            wqkv = self._stack(wq, wk, wv) if fused else None
+            if fused and _SELF_QKV and ln is not None and ops.ln_linear_ok(x, wqkv) and x.dim() == 3 and (2 * c) % 160 == 0:
+                # 64x64 level: LayerNorm + Q | K | V in ONE launch whose V third is written transposed, so that the 4096-token
+                # self-attention runs on the transposed-V flash kernel (the row-major-V variant is 10-20 % slower there)
+                qk, vt = ops.ln_linear(x, ln.weight, ln.bias, ln.eps, wqkv, transposed_from=2 * c)
+                out = ops.attention(qk[..., :c], qk[..., c:], vt, self.heads, x.shape[1], self.scale)
+                return ops.linear(out, _eff(self, self.to_out[0].weight, "out"), self.to_out[0].bias, residual=residual)
             if fused and _SELF_QKV:
                 # self-attention: the three projections share their input -> ONE GEMM, q / k / v are column slices of its output
-                qkv = project(self._stack(wq, wk, wv))
+                qkv = project(wqkv)
                 out = ops.attention_rows_v(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads, self.scale)
                 return ops.linear(out, _eff(self, self.to_out[0].weight, "out"), self.to_out[0].bias, residual=residual)
             if ln is not None:

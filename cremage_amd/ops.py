@@ -332,9 +332,11 @@ def ln_linear_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
 
 
 def ln_linear(x: torch.Tensor, ln_weight, ln_bias, eps: float, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-              act: Optional[str] = None) -> torch.Tensor:
+              act: Optional[str] = None, transposed_from: Optional[int] = None):
     """y = act(LayerNorm(x) @ weight^T + bias) in ONE launch (crg_ln_gemm): nn.LayerNorm + the Linear behind it.
-    act: None | 'geglu'.  Falls back to nothing - callers test ln_linear_ok() and otherwise run layer_norm + linear."""
+    act: None | 'geglu'.  Falls back to nothing - callers test ln_linear_ok() and otherwise run layer_norm + linear.
+    transposed_from = n0 (x must be [B, T, K]): output columns >= n0 are returned as a second tensor [B, N - n0, ld] with
+    ld = roundup(T, 8), i.e. transposed per sample (the V^T operand of `attention`); the first tensor then has n0 columns."""
     _need_cuda(x, ln_weight, ln_bias, weight, bias)
     if not ln_linear_ok(x, weight):
         raise L.CrgError("ln_linear: bf16 tokens of width 320 expected (use layer_norm + linear)")
@@ -346,17 +348,26 @@ def ln_linear(x: torch.Tensor, ln_weight, ln_bias, eps: float, weight: torch.Ten
     if act not in (None, "geglu"):
         raise L.CrgError(f"ln_linear: activation {act!r} unsupported")
     hi, _ = packed_weight(weight, L.PACK_GEGLU if geglu else L.PACK_LINEAR, False)
-    n_out = N // 2 if geglu else N
+    n_out = N // 2 if geglu else (transposed_from if transposed_from is not None else N)
     y = torch.empty(x.shape[:-1] + (n_out,), dtype=x.dtype, device=x.device)
     b = None
     if bias is not None:
         b = packed_geglu_bias(bias) if geglu else f32_vec(bias)
+    vt, tokens, ld = None, 0, 0
+    if transposed_from is not None:
+        if x.dim() != 3 or geglu:
+            raise L.CrgError("ln_linear: transposed_from needs [B, T, K] tokens and no activation")
+        tokens = x.shape[1]
+        ld = (tokens + 7) // 8 * 8
+        vt = torch.empty((x.shape[0], N - transposed_from, ld), dtype=x.dtype, device=x.device)
+        if ld != tokens:
+            vt[:, :, tokens:].zero_()
     a = L.LnGemmArgs(x=x.data_ptr(), ldx=K, gamma=_p(f32_vec(ln_weight)).value, beta=_p(f32_vec(ln_bias)).value, eps=float(eps),
                      w=hi.data_ptr(), ldw=K, bias=_p(b).value, y=y.data_ptr(), ldy=n_out, M=M, N=N, K=K,
-                     epilogue=L.EPI_GEGLU if geglu else L.EPI_NONE)
+                     epilogue=L.EPI_GEGLU if geglu else L.EPI_NONE, vt=_p(vt).value, vt_n0=transposed_from or 0, vt_tokens=tokens, vt_ld=ld)
     h = _h(x)
     L.check(L.load().crg_ln_gemm(h, _st(), C.byref(a)), h, "crg_ln_gemm")
-    return y
+    return (y, vt) if transposed_from is not None else y
 
 
 def linear_transposed(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -126,6 +126,10 @@ typedef struct {
   void* y; int64_t ldy;
   int M, N, K;
   int epilogue;
+  /* optional: columns n >= vt_n0 (tile aligned: multiple of 160 when N % 160 == 0, else 128) go TRANSPOSED to
+   * vt[(m / vt_tokens) * (N - vt_n0) + (n - vt_n0)][m % vt_tokens] (row length vt_ld) instead of y - the V^T operand of
+   * crg_attention, emitted by the same launch as Q | K.  vt == NULL: every column goes to y. */
+  void* vt; int vt_n0; int vt_tokens; int64_t vt_ld;
 } crg_lngemm_args;
 int crg_ln_gemm(crg_ctx* ctx, void* stream, const crg_lngemm_args* args);
 

@@ -125,6 +125,26 @@ def test_ln_linear(M, N, act, bias):
     assert d <= 2 ** -6 * max(1.0, two.float().abs().max().item()), d
 
 
+@pytest.mark.parametrize("B,T", [(2, 256), (3, 100), (8, 4096)])
+def test_ln_linear_transposed_v(B, T):
+    """crg_ln_gemm with a transposed column range: LayerNorm + Q | K | V in one launch, Q | K row-major and V as V^T [B, C, ld]
+    (what crg_attention takes) - against the two-launch form (fused Q | K GEMM + linear_transposed) on the same LN output."""
+    from cremage_amd import ops
+    K = C = 320
+    x = rnd(B, T, K, seed=150, scale=1.5) - 0.2
+    g, be = 1 + 0.2 * rnd(K, seed=151), 0.3 * rnd(K, seed=152)
+    w = rnd(3 * C, K, seed=153, scale=K ** -0.5)
+    dx, dw = x.to(_dev()).to(BF), w.to(_dev()).to(BF)
+    qk, vt = ops.ln_linear(dx, g.to(_dev()), be.to(_dev()), 1e-5, dw, transposed_from=2 * C)
+    ld = (T + 7) // 8 * 8
+    assert qk.shape == (B, T, 2 * C) and vt.shape == (B, C, ld)
+    ln = q(F.layer_norm(q(x, BF), (K,), g, be, 1e-5), BF)
+    ref = F.linear(ln, q(w, BF))
+    check(qk, ref[..., :2 * C], BF, "ln_linear qk")
+    check(vt[:, :, :T].transpose(1, 2), ref[..., 2 * C:], BF, "ln_linear v^T")
+    assert (vt[:, :, T:] == 0).all()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("T", [77, 154, 64, 1])
 def test_linear_transposed(dtype, T):
