@@ -54,6 +54,10 @@ extern "C" int crg_ctx_create(int device, crg_ctx** out) {
   crg_ctx* c = new (std::nothrow) crg_ctx();
   if (!c) return -12;
   c->device = device;
+  {
+    hipDeviceProp_t prop;
+    c->n_cu = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 0;
+  }
   if (hipMalloc(&c->zero_page, 4096 + 16384) != hipSuccess || hipMemset(c->zero_page, 0, 4096 + 16384) != hipSuccess) {
     delete c;
     return -12;

@@ -29,6 +29,7 @@ struct crg_prof_rec {
 
 struct crg_ctx {
   int device = 0;
+  int n_cu = 0;  // compute units of the device (residency bound of the kernels whose blocks wait for each other)
   std::string err;
   void* scratch = nullptr;
   size_t scratch_bytes = 0;

@@ -1101,7 +1101,7 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     static const int inred = getenv("CRG_INRED") ? atoi(getenv("CRG_INRED")) : 0;   // dev knob: most K slices summed in-kernel.  Default 0 = always the reduce kernel: measured SLOWER in-kernel (8x32x32 640->640 72.0 -> 78.7 us, 8x16x16 1280->1280 69.1 -> 76.4 us: 160 KB of fp32 per slice and tile is far past the few tens of KB where the guide says an in-launch seam pays)
     if (p.rowhalo == 2 && ring && p.a_bytes && p.w_bytes && (p.C2 == 0 || p.x2_bytes) && (long)p.M / (p.Ho * p.Wo) * p.H * p.W < (1 << 24)) {
       p.ring = ring;
-      if (p.splits > 1 && p.splits <= inred && p.tiles_m * p.tiles_n <= 4096 && (p.N & 3) == 0) {
+      if (p.splits > 1 && p.splits <= inred && p.tiles_m * p.tiles_n <= 2048 && (p.N & 3) == 0) {
         p.inred = 1;
         p.tile_cnt = ctx->tile_cnt;
       }

@@ -232,6 +232,12 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
+// (A one-launch form for the 64x64 / 32x32 levels - rows kept in registers, per-sample arrival counters between the blocks,
+//  write-through partials, no release fence - was built and measured in round 2: correct and bitwise deterministic, but
+//  34.9 us against 18.2 us for the stats + apply pair on 8 x 320 x 64 x 64: waiting for the other blocks of the sample costs
+//  far more than the kernel boundary it replaces, exactly as the guide's price list says (barrier-counter 12.7 us at two
+//  workgroups per CU vs boundary 1.7 us).  Removed; the pair below stays.)
+
 // ---- GroupNorm, small images (8x8 / 16x16 UNet levels): ONE launch, one block per (sample, group) ----
 // The group's HW x gs slab (gs % 8 == 0, at most 256 * VPT 16-byte vectors) is read once into registers, reduced
 // (shifted sums, wave shuffles + a fixed-order cross-wave sum: deterministic), normalised and written back.  Replaces the

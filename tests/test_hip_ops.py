@@ -404,6 +404,26 @@ def test_group_norm_golden(dtype, tag):
         assert rel < (1e-5 if dtype == torch.float32 else 6e-3), (tag, silu, rel)
 
 
+@pytest.mark.parametrize("N,C1,C2,hw,silu", [(8, 320, 0, 64, True), (8, 640, 0, 32, True), (8, 320, 0, 64, False), (8, 320, 320, 64, True),
+                                               (2, 320, 0, 64, True), (8, 1280, 640, 32, True), (3, 320, 0, 40, True), (8, 640, 320, 64, True)])
+def test_group_norm_production_shapes(N, C1, C2, hw, silu):
+    """GroupNorm(+SiLU) at the 64x64 / 32x32 levels' production shapes (stats + apply pair): virtual concat, a ragged size,
+    repeated calls and bitwise run-to-run determinism (fixed-order reductions, no float atomics)."""
+    from cremage_amd import ops
+    C = C1 + C2
+    x = rnd(N, C1, hw, hw, seed=160, scale=2.0) + 1.5
+    x2 = (rnd(N, C2, hw, hw, seed=161, scale=0.5) - 2.0) if C2 else None
+    g, b = 1 + 0.1 * rnd(C, seed=162), 0.1 * rnd(C, seed=163)
+    xx = q(x, BF) if x2 is None else torch.cat([q(x, BF), q(x2, BF)], dim=1)
+    ref = F.group_norm(xx, 32, g, b, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    dx, dx2 = nhwc(x, BF), (nhwc(x2, BF) if C2 else None)
+    outs = [ops.group_norm(dx, g.to(_dev()), b.to(_dev()), 32, 1e-5, silu=silu, x2=dx2) for _ in range(3)]
+    check(outs[0], ref, BF, f"gn single launch {N}x{C1}+{C2}x{hw}")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_group_norm_concat(dtype):
     from cremage_amd import ops
