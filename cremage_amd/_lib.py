@@ -51,6 +51,7 @@ class LnGemmArgs(C.Structure):
         ("M", c_int), ("N", c_int), ("K", c_int),
         ("epilogue", c_int),
         ("vt", c_void_p), ("vt_n0", c_int), ("vt_tokens", c_int), ("vt_ld", c_int64),
+        ("residual", c_void_p), ("ldr", c_int64),
     ]
 
 

@@ -21,6 +21,7 @@ struct LnGemmP {
   const float* gamma; const float* beta; float eps;
   const bf16* w; long ldw;     // packed [N][K] (GEGLU: value / gate rows interleaved in 16-row groups, crg_pack_weight)
   const float* bias;           // fp32 [N] (GEGLU: packed like the rows) or null
+  const bf16* res; long ldr; unsigned res_bytes;  // optional residual [M][ldr] added after the bias (plain epilogue only)
   bf16* y; long ldy;
   int M, N, K, epi;
   unsigned x_bytes, w_bytes, y_bytes;
@@ -59,6 +60,25 @@ static __device__ __forceinline__ void ln_store8(void* base, unsigned bytes, int
   __builtin_memcpy(&r, &v, 8);
   __builtin_amdgcn_raw_buffer_store_b64(r, rs, voff, 0, 0);
 #endif
+}
+
+static __device__ __forceinline__ bf16x8 ln_load16(const void* base, unsigned bytes, int voff) {
+  bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+  __builtin_memcpy(&v, &r, 16);
+#endif
+  return v;
+}
+static __device__ __forceinline__ bf16x4 ln_load8(const void* base, unsigned bytes, int voff) {
+  bf16x4 v = {0, 0, 0, 0};
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+  const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
+  __builtin_memcpy(&v, &r, 8);
+#endif
+  return v;
 }
 
 static __device__ __forceinline__ void ln_store2(void* base, unsigned bytes, int voff, bf16 v) {
@@ -183,7 +203,8 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
   if (U > 2) stage_w(2);
 
   // ---- LayerNorm of the resident rows, in place: wave w owns rows 16 w .. 16 w + 15, 8 lanes per row ----
-  {
+  // (gamma == null: no LayerNorm - the kernel is then a plain row-resident GEMM for K = 320)
+  if (p.gamma) {
     const int c = lane & 7, r8 = lane >> 3;
     f32x4 g0[KT], g1[KT], b0[KT], b1[KT];
 #pragma unroll
@@ -370,7 +391,15 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
 #pragma unroll
           for (int j = 0; j < WMT; ++j) {
             const int m = m0 + wm * 32 + j * 16 + frow;
-            const f32x4 a4 = acc[2 * u2][j] + ba, b4 = acc[2 * u2 + 1][j] + bb;
+            f32x4 a4 = acc[2 * u2][j] + ba, b4 = acc[2 * u2 + 1][j] + bb;
+            if (p.res) {  // out-of-range lanes read zeros (range check) and are dropped by the store below
+              const bf16x8 r8 = ln_load16(p.res, p.res_bytes, (nok && m < p.M) ? (int)(((long)m * p.ldr + n) * 2) : OOBS);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                a4[e] += (float)r8[e];
+                b4[e] += (float)r8[4 + e];
+              }
+            }
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -388,7 +417,12 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
 #pragma unroll
           for (int j = 0; j < WMT; ++j) {
             const int m = m0 + wm * 32 + j * 16 + frow;
-            const f32x4 a4 = acc[WNT - 1][j] + ba;
+            f32x4 a4 = acc[WNT - 1][j] + ba;
+            if (p.res) {
+              const bf16x4 r4 = ln_load8(p.res, p.res_bytes, (nok && m < p.M) ? (int)(((long)m * p.ldr + n) * 2) : OOBS);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) a4[e] += (float)r4[e];
+            }
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16)a4[e];
@@ -416,7 +450,7 @@ extern "C" int crg_ln_gemm(crg_ctx* ctx, void* stream, const crg_lngemm_args* a)
               (long)a->ldx, (long)a->ldw);
   CRG_REQUIRE(ctx, (((uintptr_t)a->x | (uintptr_t)a->w | (uintptr_t)a->y | (uintptr_t)a->gamma | (uintptr_t)a->beta | (uintptr_t)a->bias) & 15) == 0,
               "ln_gemm: pointers must be 16-byte aligned");
-  CRG_REQUIRE(ctx, a->gamma && a->beta, "ln_gemm: gamma / beta are required");
+  CRG_REQUIRE(ctx, (a->gamma == nullptr) == (a->beta == nullptr), "ln_gemm: gamma and beta come together (both NULL: no LayerNorm)");
   const bool geglu = a->epilogue == CRG_EPI_GEGLU;
   CRG_REQUIRE(ctx, a->epilogue == CRG_EPI_NONE || geglu, "ln_gemm: epilogue %d unsupported", a->epilogue);
   if (geglu) CRG_REQUIRE(ctx, a->N % 32 == 0, "ln_gemm: GEGLU needs packed N %% 32 == 0 (got %d)", a->N);
@@ -427,6 +461,13 @@ extern "C" int crg_ln_gemm(crg_ctx* ctx, void* stream, const crg_lngemm_args* a)
   p.w = (const bf16*)a->w; p.ldw = a->ldw; p.bias = a->bias; p.y = (bf16*)a->y; p.ldy = a->ldy;
   p.M = a->M; p.N = a->N; p.K = a->K; p.epi = a->epilogue;
   p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+  if (a->residual) {
+    CRG_REQUIRE(ctx, !geglu && !a->vt, "ln_gemm: the residual belongs to the plain epilogue");
+    CRG_REQUIRE(ctx, a->ldr % 8 == 0 && a->ldr >= a->N && ((uintptr_t)a->residual & 15) == 0, "ln_gemm: residual rows must be 16-byte aligned and >= N wide");
+    const double rb = (double)a->M * a->ldr * 2.0;
+    CRG_REQUIRE(ctx, rb < 2147483648.0, "ln_gemm: residual must be < 2 GiB");
+    p.res = (const bf16*)a->residual; p.ldr = a->ldr; p.res_bytes = (unsigned)rb;
+  }
   if (a->vt) {
     CRG_REQUIRE(ctx, !geglu, "ln_gemm: a transposed column range and GEGLU do not combine");
     CRG_REQUIRE(ctx, a->vt_n0 > 0 && a->vt_n0 < a->N && a->vt_tokens > 0 && a->M % a->vt_tokens == 0 && a->vt_ld >= a->vt_tokens,

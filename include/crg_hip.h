@@ -116,6 +116,7 @@ int crg_layernorm(crg_ctx* ctx, void* stream, const void* x, const float* gamma,
  * X is read once and LN(X) never reaches HBM.  bf16 in / out, fp32 statistics (two-pass, as crg_layernorm).
  *   x: bf16 [M][ldx];  gamma, beta: fp32 [K];  w: bf16 [N][ldw] (crg_pack_weight; GEGLU: CRG_PACK_GEGLU);  bias: fp32 [N]
  *   (GEGLU: crg_pack_geglu_bias) or NULL;  y: bf16 [M][ldy];  epilogue: CRG_EPI_NONE | CRG_EPI_GEGLU (then y is [M][N/2]).
+ * gamma == beta == NULL: no LayerNorm (plain GEMM on the same row-resident kernel, e.g. to_out + residual).
  * Built for K == 320 (the 64x64 level of SD1.5, where these GEMMs have five k-tiles and are launch / latency bound);
  * other K return an error: the caller uses crg_layernorm + crg_gemm. */
 typedef struct {
@@ -130,6 +131,9 @@ typedef struct {
    * vt[(m / vt_tokens) * (N - vt_n0) + (n - vt_n0)][m % vt_tokens] (row length vt_ld) instead of y - the V^T operand of
    * crg_attention, emitted by the same launch as Q | K.  vt == NULL: every column goes to y. */
   void* vt; int vt_n0; int vt_tokens; int64_t vt_ld;
+  /* optional residual [M][ldr] (bf16) added after the bias (plain epilogue only): to_out / proj_out + skip (attention.py:685-693,1049-1057).
+   * With gamma == beta == NULL the LayerNorm is skipped and the kernel is a row-resident GEMM for K = 320. */
+  const void* residual; int64_t ldr;
 } crg_lngemm_args;
 int crg_ln_gemm(crg_ctx* ctx, void* stream, const crg_lngemm_args* args);
 

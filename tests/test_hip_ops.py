@@ -125,6 +125,21 @@ def test_ln_linear(M, N, act, bias):
     assert d <= 2 ** -6 * max(1.0, two.float().abs().max().item()), d
 
 
+@pytest.mark.parametrize("M,N,bias,res", [(4096, 320, True, True), (5000, 320, True, False), (1024, 640, False, True)])
+def test_row_resident_gemm_without_layernorm(M, N, bias, res):
+    """crg_ln_gemm with gamma = beta = NULL (no LayerNorm) + residual: the row-resident kernel as a plain K = 320 GEMM
+    (ops.ln_linear(x, None, None, ...); not routed by default - measured equal to crg_gemm on these shapes)."""
+    from cremage_amd import ops
+    K = 320
+    x, w = rnd(M, K, seed=155), rnd(N, K, seed=156, scale=K ** -0.5)
+    b = rnd(N, seed=157, scale=0.2) if bias else None
+    r = rnd(M, N, seed=158) if res else None
+    ref = F.linear(q(x, BF), q(w, BF), b) + (q(r, BF) if res else 0.0)
+    got = ops.ln_linear(x.to(_dev()).to(BF), None, None, 0.0, w.to(_dev()).to(BF), b.to(_dev()) if bias else None,
+                        residual=r.to(_dev()).to(BF) if res else None)
+    check(got, ref, BF, f"row-resident gemm {M}x{N}")
+
+
 @pytest.mark.parametrize("B,T", [(2, 256), (3, 100), (8, 4096)])
 def test_ln_linear_transposed_v(B, T):
     """crg_ln_gemm with a transposed column range: LayerNorm + Q | K | V in one launch, Q | K row-major and V as V^T [B, C, ld]
