@@ -1,11 +1,17 @@
 """Block- and model-level parity on a real MI355X against the GOLDEN VECTORS produced by the
 reference's own modules (tests/golden/, oracle/gen_golden.py), in both precision configurations:
 
-  fp32-class (fp32 activations, split-bf16 x3 MFMA)   tolerance: rel-L2 <= 2e-4 (blocks), 1e-3 (nets)
-  bf16       (bf16 activations/weights, fp32 accum)    tolerance: rel-L2 <= 2e-2 (blocks), 4e-2 (nets)
+  fp32-class (fp32 activations, split-bf16 x3 MFMA)   tolerance: rel-L2 <= 1.6e-5 (blocks), 5e-5 (nets)
+  bf16       (bf16 activations/weights, fp32 accum)    tolerance: rel-L2 <= 1.0e-2 (blocks), 2.5e-2 (nets)
+
+Every bound is 1.5x the largest error MEASURED in its class on MI355X (round 2, CRG_TOL_REPORT=1 prints one line per
+comparison: blocks fp32-class 1.04e-5 / bf16 6.6e-3, nets 3.0e-5 / 1.64e-2, SDXL nets bf16 2.17e-2, trajectories 6.0e-5):
+a 2x regression fails.
 
 and, for the VAE decoder, the north-star pixel bound: L-inf <= 1e-3 on clamp((x+1)/2, 0, 1).
 """
+import os
+
 import pytest
 import torch
 
@@ -15,8 +21,10 @@ from tests.conftest import load_golden, rel_l2
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
 DEV = "cuda:0"
-TOL_BLOCK = {torch.float32: 2e-4, BF: 2e-2}
-TOL_NET = {torch.float32: 1e-3, BF: 4e-2}
+TOL_BLOCK = {torch.float32: 1.6e-5, BF: 1.0e-2}
+TOL_NET = {torch.float32: 5e-5, BF: 2.5e-2}
+TOL_SDXL_BF16 = 3.3e-2   # SDXL nets in bf16 (measured 2.17e-2 small / 1.74e-2 full size)
+TOL_TRAJ = 1e-4          # fp32-class sampler trajectories, latents (measured <= 6.0e-5)
 
 
 def prep(module, meta, dtype):
@@ -35,6 +43,8 @@ def close(got, ref, tol, what):
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     assert torch.isfinite(got).all(), what
     r = rel_l2(got, ref)
+    if os.environ.get("CRG_TOL_REPORT"):  # dev: one line per comparison, to set the tolerances from measurements
+        print(f"\n[tol] {what}: rel-L2 {r:.3e} (bound {tol:.1e}, ratio {r / tol:.2f})")
     assert r < tol, (what, r, tol)
     return r
 
@@ -308,7 +318,7 @@ def test_vae_sd15_full_encode():
     x = synth_input("vae_full.img", (1, 3, 256, 256), meta["seed"], 0.5).clamp(-1, 1).to(DEV)
     with torch.no_grad():
         mom = m.encode(x).parameters
-    close(mom, g["moments"], 1e-3, "vae full encode")
+    close(mom, g["moments"], TOL_NET[torch.float32], "vae full encode")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, BF])
@@ -347,11 +357,7 @@ def test_sgm_vae_full_decode_1024():
     x = synth_input("sgm_vae_full.img", (1, 3, 256, 256), meta["seed"], 0.5).clamp(-1, 1).to(DEV)
     with torch.no_grad():
         mom = m.encode(x).parameters
-    close(mom, g["moments"], 1e-3, "sgm vae full encode")
-
-
-# measured on MI355X (this file's print lines, round 2); the asserts are 1.5x these
-C1_MEASURED = {"fp32": dict(latent=None, pix=None), "bf16": dict(latent=None, pix=None)}
+    close(mom, g["moments"], TOL_NET[torch.float32], "sgm vae full encode")
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
@@ -397,9 +403,10 @@ def test_c1_sd15_full_20_step_trajectory(mode):
           f"{drift[5]:.3e} / {drift[10]:.3e} / {drift[15]:.3e} / {lat:.3e}; pixel L-inf {pix.max().item():.3e} "
           f"(exact fp32 subsample {sub:.3e}), pixel mean-abs {pix.mean().item():.3e}")
     if mode == "fp32":
-        assert lat < 3e-3 and sub < 3e-3, (lat, sub)
+        assert lat < 1.4e-4 and sub < 2.5e-4, (lat, sub)   # measured 9.0e-5 / 1.62e-4
     else:
-        assert lat < 0.15 and pix.mean().item() < 3e-2, (lat, pix.mean().item())
+        # measured: latent rel-L2 6.47e-2, pixel mean-abs 1.51e-2, pixel L-inf 0.133 (bf16 UNet x 20 steps; the VAE is fp32-class)
+        assert lat < 9.7e-2 and pix.mean().item() < 2.3e-2 and pix.max().item() < 0.2, (lat, pix.mean().item(), pix.max().item())
 
 
 @pytest.mark.parametrize("nm", ["euler", "euler_a"])
@@ -416,7 +423,7 @@ def test_trajectory(nm):
     noises = iter([synth_input(f"traj.noise{i}", (B, 4, L, L), seed).to(DEV) for i in range(5)])
     images, x = P.txt2img(ldm, c, uc, steps=meta["S"], sampler=nm, cfg_scale=meta["cfg"], height=8 * L, width=8 * L, x0=x0,
                           noise_sampler=(lambda s, sn: next(noises)))
-    close(x, g["x"], 2e-3, "traj latent " + nm)
+    close(x, g["x"], TOL_TRAJ, "traj latent " + nm)
     ref_img = ((g["img"] + 1) / 2).clamp(0, 1)
     assert (images.cpu() - ref_img).abs().max().item() < 2e-3
 
@@ -432,8 +439,8 @@ def test_trajectory_hires_latent():
     noise = synth_input("hires.noise", (B, 4, f * L, f * L), seed).to(DEV)
     images, x, base = P.txt2img_hires(ldm, c, uc, steps=meta["S"], sampler="euler", cfg_scale=meta["cfg"], height=8 * L, width=8 * L,
                                       factor=f, strength=meta["strength"], x0=x0, fwd_noise=noise)
-    close(base, g["base"], 2e-3, "hires base latent")
-    close(x, g["x"], 3e-3, "hires latent")
+    close(base, g["base"], TOL_TRAJ, "hires base latent")
+    close(x, g["x"], TOL_TRAJ, "hires latent")
     ref_img = ((g["img"] + 1) / 2).clamp(0, 1)
     assert (images.cpu() - ref_img).abs().max().item() < 3e-3
 
@@ -451,7 +458,7 @@ def test_trajectory_ddim_img2img():
     # S=20, t_enc=3 <=> strength 0.15 (int(0.15*20) = 3, image_generator.py:727)
     images, x = P.img2img(ldm, img_in, c, uc, steps=meta["S"], strength=0.15, cfg_scale=meta["cfg"], enc_noise=enc_noise,
                           fwd_noise=fwd_noise)
-    close(x, g["x"], 2e-3, "ddim latent")
+    close(x, g["x"], TOL_TRAJ, "ddim latent")
     ref_img = ((g["img"] + 1) / 2).clamp(0, 1)
     assert (images.cpu() - ref_img).abs().max().item() < 2e-3
 
@@ -471,7 +478,7 @@ def test_sgm_unet_small(dtype, name):
     y = synth_input(name + ".y", (meta["B"], cfg["adm_in_channels"]), meta["seed"]).to(DEV)
     with torch.no_grad():
         out = m(x, timesteps=g["t"].to(DEV), context=ctx, y=y)
-    close(out, g["y"], TOL_NET[dtype] * (2 if dtype == BF else 1), name)
+    close(out, g["y"], TOL_SDXL_BF16 if dtype == BF else TOL_NET[dtype], name)
 
 
 def test_sdxl_trajectory_euler_edm():
@@ -488,7 +495,7 @@ def test_sdxl_trajectory_euler_edm():
     uc = {"crossattn": synth_input("sgmtraj.uc", (B, 77, 128), seed).to(DEV), "vector": synth_input("sgmtraj.ucv", (B, 96), seed).to(DEV)}
     x0 = synth_input("sgmtraj.x0", (B, 4, L, L), seed).to(DEV)
     x = eng.sample(x0, c, uc, meta["S"], meta["cfg"])
-    close(x, g["x"], 2e-3, "sdxl traj latent")
+    close(x, g["x"], TOL_TRAJ, "sdxl traj latent")
     img = eng.decode_first_stage(x)
     assert (img.cpu() - g["img"]).abs().max().item() < 4e-3
 
@@ -508,9 +515,9 @@ def test_sdxl_img2img_trajectory():
     uc = {"crossattn": synth_input("sgmi2i.uc", (B, 77, 128), seed).to(DEV), "vector": synth_input("sgmi2i.ucv", (B, 96), seed).to(DEV)}
     img = synth_input("sgmi2i.img", (B, 3, 2 * L, 2 * L), seed, 0.5).clamp(-1, 1).to(DEV)
     en, fn = synth_input("sgmi2i.enc_noise", (B, 4, L, L), seed).to(DEV), synth_input("sgmi2i.noise", (B, 4, L, L), seed).to(DEV)
-    close(eng.encode_first_stage(img, en), g["z"], 1e-3, "sdxl img2img z")
+    close(eng.encode_first_stage(img, en), g["z"], TOL_NET[torch.float32], "sdxl img2img z")
     images, x = P.img2img_sdxl(eng, img, c, uc, steps=meta["S"], strength=meta["strength"], cfg_scale=meta["cfg"], enc_noise=en, fwd_noise=fn)
-    close(x, g["x"], 2e-3, "sdxl img2img latent")
+    close(x, g["x"], TOL_TRAJ, "sdxl img2img latent")
     ref = ((g["img"] + 1) / 2).clamp(0, 1)
     assert (images.cpu() - ref).abs().max().item() < 2e-3
 
@@ -530,14 +537,14 @@ def test_c5_chain_txt2img_then_facefix_reentry():
     boxes = [tuple(b) for b in meta["boxes"]]
     # the two passes use different step counts in the fixture (5 then 10 x 0.3): run them as the pipeline does, one call each
     first, x1 = P.txt2img_sdxl(eng, c, uc, steps=meta["S1"], cfg_scale=meta["cfg"], height=2 * L, width=2 * L, x0=x0)
-    close(x1, g["x1"], 2e-3, "c5 first-pass latent")
+    close(x1, g["x1"], TOL_TRAJ, "c5 first-pass latent")
     assert (first.cpu() - g["first"]).abs().max().item() < 2e-3
     import torch.nn.functional as F
     crops = torch.stack([F.interpolate(first[i:i + 1, :, t:t + sz, l:l + sz], size=(2 * L, 2 * L), mode="bilinear", align_corners=False)[0]
                          for i, (t, l, sz) in enumerate(boxes)])
     fixed, x2 = P.img2img_sdxl(eng, crops * 2.0 - 1.0, c, uc, steps=meta["S2"], strength=meta["strength"], cfg_scale=meta["cfg"],
                                enc_noise=en, fwd_noise=fn)
-    close(x2, g["x2"], 3e-3, "c5 second-pass latent")
+    close(x2, g["x2"], TOL_TRAJ, "c5 second-pass latent")
     assert (fixed.cpu() - g["fixed"]).abs().max().item() < 3e-3
     # and the one-call form (same step count for both passes, as the application runs it) is self-consistent with its parts
     out, f1, f2 = P.txt2img_sdxl_facefix(eng, c, uc, boxes, steps=meta["S2"], cfg_scale=meta["cfg"], height=2 * L, width=2 * L,
@@ -569,7 +576,7 @@ def test_sgm_unet_sdxl_full(dtype):
     y = synth_input(name + ".y", (2, 2816), meta["seed"]).to(DEV)
     with torch.no_grad():
         out = m(x, timesteps=g["t"].to(DEV), context=ctx, y=y)
-    r = close(out, g["y"], 8e-2, name)
+    r = close(out, g["y"], TOL_SDXL_BF16, name)
     print(f"\n[parity] SDXL UNet full {dtype}: rel-L2 {r:.3e}, max-abs {(out.cpu() - g['y']).abs().max().item():.3e} "
           f"(|ref| max {g['y'].abs().max().item():.3f})")
 
@@ -709,7 +716,7 @@ def test_reference_gpu_calling_convention_half_autocast():
     vae.compute_dtype = torch.float32
     with torch.no_grad():
         dec32 = vae.decode(z)
-    close(dec32, vg["dec"], 2e-3, "vae half params, fp32-class compute")
+    close(dec32, vg["dec"], 1.1e-3, "vae half params, fp32-class compute")  # measured 7.1e-4 (the PARAMETERS are fp16-rounded here)
 
 
 def test_c4_unit_img2img_768_properties():
