@@ -142,11 +142,22 @@ def load():
 
 
 _ctxs = {}
+_lane = 0
+
+
+def set_lane(i: int) -> int:
+    """Select which of the device's contexts the following crg_* calls use.  A context owns scratch (split-K slabs, GroupNorm
+    partials) and is not re-entrant, so work that runs CONCURRENTLY on several HIP streams needs one context per stream
+    ("lane"); the single-stream caller never touches this.  Returns the previous lane."""
+    global _lane
+    prev, _lane = _lane, int(i)
+    return prev
 
 
 def ctx(device_index: int):
-    """One context per device (include/crg_hip.h: not re-entrant, single-threaded caller)."""
-    h = _ctxs.get(device_index)
+    """One context per (device, lane) (include/crg_hip.h: not re-entrant, single-threaded caller; lane 0 unless set_lane)."""
+    key = (device_index, _lane)
+    h = _ctxs.get(key)
     if h is None:
         lib = load()
         out = c_void_p()
@@ -154,7 +165,7 @@ def ctx(device_index: int):
         if rc != 0:
             raise CrgError(f"crg_ctx_create(device={device_index}) failed with {rc}: no usable HIP device")
         h = out
-        _ctxs[device_index] = h
+        _ctxs[key] = h
     return h
 
 
