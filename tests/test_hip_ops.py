@@ -540,6 +540,30 @@ def test_flash_attention_row_major_v_spiky_rows():
     assert ((got - ref).norm() / ref.norm()).item() < 1e-2
 
 
+@pytest.mark.parametrize("heads,d,Nq,Nk", [(8, 40, 200, 192), (3, 48, 130, 64), (8, 40, 384, 1024), (2, 40, 128, 2048), (4, 64, 256, 256),
+                                           (2, 64, 130, 192), (8, 80, 200, 128), (8, 80, 128, 320), (2, 80, 300, 1024)])
+def test_flash_attention_lds_dma_form(heads, d, Nq, Nk):
+    """attn_dma_kernel / attn_sp_kernel (whole 64-key tiles, K / V^T staged by LDS-DMA with the key permutation and the chunk swizzles;
+    Nk % 128 == 0 takes the software-pipelined form, odd tile counts the plain one): q and k are column slices of a wider NaN-filled
+    buffer (nothing outside the head's own channels may be read into a product), query tails, many key tiles (every stage reused),
+    head dims 40 / 64 / 80 (each has its own K-image swizzle), and 48, which stays on the register-staged kernel."""
+    from cremage_amd import ops
+    C = heads * d
+    qq, kk, vv = rnd(2, Nq, C, seed=270), rnd(2, Nk, C, seed=271), rnd(2, Nk, C, seed=272)
+    kk[1, Nk - 3] = qq[1, 5] * 5.0  # a late dominant key: the rescale branch
+    ref = attn_ref(q(qq, BF), q(kk, BF), q(vv, BF), heads, d ** -0.5)
+    wide_q = torch.full((2, Nq, C + 16), float("nan"))
+    wide_k = torch.full((2, Nk, C + 24), float("nan"))
+    wide_q[..., 8:8 + C] = qq
+    wide_k[..., 8:8 + C] = kk
+    dq = wide_q.to(_dev()).to(BF)[..., 8:8 + C]
+    dk = wide_k.to(_dev()).to(BF)[..., 8:8 + C]
+    vt = vv.transpose(1, 2).contiguous().to(_dev()).to(BF)
+    got = ops.attention(dq, dk, vt, heads, Nk, d ** -0.5).float().cpu()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert torch.isfinite(got).all() and rel < 1e-2, (rel, heads, d, Nq, Nk)
+
+
 def test_flash_attention_spiky_rows():
     """online-softmax rescale path: one key dominates late in the sequence (guide rule 26)"""
     from cremage_amd import ops
