@@ -144,6 +144,16 @@ static __device__ __forceinline__ void ln_wait(int n) {  // wave-uniform s_waitc
   }
 }
 
+// s_waitcnt vmcnt(nW + EXTRA) for the per-wave batch sizes that occur (WRG / 8 rounded either way): two scalar branches instead of
+// the table's compare tree in front of every k-tile's barrier
+template <int EXTRA>
+static __device__ __forceinline__ void ln_wait_nw(int nW) {
+  if (nW == 2) wait_vmcnt<2 + EXTRA>();
+  else if (nW == 3) wait_vmcnt<3 + EXTRA>();
+  else if (nW == 1) wait_vmcnt<1 + EXTRA>();
+  else ln_wait(nW + EXTRA);
+}
+
 template <int WNT, int KT, bool GEGLU>
 __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
   constexpr bool PAIR = !GEGLU;  // plain outputs use the paired column mapping (16-byte stores); GEGLU its own [v16 | g16] packing
@@ -198,9 +208,11 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
     for (int q = 0; q < WL; ++q)
       if ((wave + NW * q) < WRG) ln_dma16(p.w, p.w_bytes, ws + (wave + NW * q) * 1024, wvo[q], soff);
   };
+  // (weight k-tiles past the last one: their rows lie beyond w_bytes, the DMA writes zeros into slots nobody reads - issuing them
+  // anyway keeps every wait of the loop at its steady-state count and every fragment read unconditional)
   stage_w(0);
-  if (U > 1) stage_w(1);
-  if (U > 2) stage_w(2);
+  stage_w(1);
+  stage_w(2);
 
   // ---- LayerNorm of the resident rows, in place: wave w owns rows 16 w .. 16 w + 15, 8 lanes per row ----
   // (gamma == null: no LayerNorm - the kernel is then a plain row-resident GEMM for K = 320)
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
     }
     // the rows (older than the three weight batches) have landed once at most 3 nW operations of this wave are outstanding;
     // the gamma / beta loads above are younger still, the compiler waits for them itself at their first use
-    ln_wait(nW * (U < 3 ? U : 3));
+    ln_wait(nW * 3);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
   };
   {
     // weight k-tile 0 landed (two batches may stay in flight); this barrier also publishes the normalised rows
-    ln_wait(nW * (U > 2 ? 2 : U - 1));
+    ln_wait(nW * 2);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -308,18 +320,36 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
       // still in the queue only make the wait err on the safe side
       // ... and the NST stores of the previous n-tile's epilogue, issued between the batches of k-tiles u_e + 3 and u_e + 4
       // (u_e = that n-tile's last k-tile), are younger than what the first two waits of an n-tile need: they stay in flight too
-      ln_wait((u + 2 < U ? nW : 0) + ((kt < 2 && nt > 0) ? ((!GEGLU && p.vt && (nt - 1) * BN >= p.vt_n0) ? NSTT : NST) : 0));
+      if (kt < 2 && nt > 0) {
+        if (!GEGLU && p.vt && (nt - 1) * BN >= p.vt_n0) ln_wait_nw<NSTT>(nW);
+        else ln_wait_nw<NST>(nW);
+      } else {
+        ln_wait_nw<0>(nW);
+      }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      // (ablation builds -DCRG_LN_ABL_NOMMA / -DCRG_LN_ABL_NODMA, N = 2560 GEGLU: 87 us full, 82 without the DMA, 66 without the
+      // MFMAs, 53 without either: barrier + fragment reads + prologue / epilogue are the larger part.  Running the two waves of a
+      // SIMD in opposite orders - w + 4 issues its first MFMA block before its fragment reads - measured 88 -> 91 us, not kept.)
       read_frags(xf1, wf1, kt, u & 3, 1);
       __builtin_amdgcn_sched_barrier(0);
+#ifndef CRG_LN_ABL_NOMMA
       mma(xf0, wf0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
-      if (u + 3 < U) stage_w(u + 3);  // slot of k-tile u - 1: every wave finished reading it before this k-tile's barrier
-      if (u + 1 < U) read_frags(xf0, wf0, kt + 1 < KT ? kt + 1 : 0, (u + 1) & 3, 0);
+#ifndef CRG_LN_ABL_NODMA
+      stage_w(u + 3);  // slot of k-tile u - 1: every wave finished reading it before this k-tile's barrier
+#endif
+      // unconditional (after the last k-tile it reads a slot of zeros): behind a branch the compiler cannot count these reads and
+      // makes the MFMAs below wait for lgkmcnt(0), i.e. for the prefetch as well as for their own operands
+      read_frags(xf0, wf0, kt + 1 < KT ? kt + 1 : 0, (u + 1) & 3, 0);
       __builtin_amdgcn_sched_barrier(0);
+#ifndef CRG_LN_ABL_NOMMA
       mma(xf1, wf1);
+#else
+      asm volatile("" ::"v"(xf1[0]), "v"(wf1[0]), "v"(xf0[0]), "v"(wf0[0]));
+#endif
     }
     // ---- epilogue of n-tile nt (the ring keeps filling underneath): exactly NST store instructions per wave ----
     {
@@ -436,6 +466,7 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
 #pragma unroll
       for (int j = 0; j < WMT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  wait_vmcnt<0>();  // the (zero-fill) DMA batches issued past the last k-tile must land before this block's LDS is handed on
 }
 
 }  // namespace crg_mm
