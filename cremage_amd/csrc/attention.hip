@@ -686,6 +686,17 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_sp_kernel(AttnP p, unsigned
   constexpr int NI = 2 * KC;  // DMA pieces per iteration: K(t+2) and V^T(t)
   constexpr int NQ = (NI + NW - 1) / NW;
   constexpr int Dh = KC * 8;
+  // Dh = 8 (mod 16): the last k-step of Q K^T has eight padded channels.  They carry the softmax's shift: Q is pre-multiplied by
+  // scale * log2(e) when its fragments are loaded and its channel Dh holds -m_ref, K's channels Dh.. read a chunk of ones, so the MFMA
+  // delivers s * scale * log2(e) - m_ref and P = exp2 of it directly - no v_fma per score.  m_ref (per query, bf16-exact) follows the
+  // row maximum lazily: it moves only when a tile's maximum exceeds it by more than QPAD_T (P then stays below 2^QPAD_T), which
+  // costs that tile one subtraction per score and the accumulators one rescale; always on the first tile.
+#ifdef CRG_ATTN_NO_QPAD
+  constexpr bool QPAD = false;
+#else
+  constexpr bool QPAD = (KC & 1) && ONES;
+#endif
+  constexpr float QPAD_T = 10.0f;
   __shared__ __attribute__((aligned(256))) char smem[2 * KBYTES + 2 * VBYTES];  // [K0][K1][V0][V1]
 
   const int t = threadIdx.x;
@@ -756,8 +767,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_sp_kernel(AttnP p, unsigned
     for (int s = 0; s < KS; ++s) {
       const int d0 = 16 * s + 8 * hh;
       qf[s] = (query < p.Nq && d0 < Dh) ? *reinterpret_cast<const bf16x8*>(Q + (long)query * p.ldq + d0) : zero8;
+      if (QPAD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[s][j] = (bf16)((float)qf[s][j] * p.scale_log2);
+      }
     }
   }
+  float m_ref = 0.f;  // QPAD: the shift currently stored (negated) in channel Dh of the Q fragments
   f32x16 oacc[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i)
@@ -769,6 +785,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_sp_kernel(AttnP p, unsigned
 
   const int kaddr = r * (KC * 16) + ((hh ^ AttnKSwz<KC>::of(r)) << 4);
   const int kaddr_last = (KC & 1) ? r * (KC * 16) : kaddr;
+  const int ones_addr = 2 * KBYTES + Dh * 128;  // V^T stage 0, row Dh: 64 x 1.0 (written once, never overwritten by the DMA)
   int vaddr[NV];
 #pragma unroll
   for (int dv = 0; dv < NV; ++dv) {
@@ -787,7 +804,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_sp_kernel(AttnP p, unsigned
       for (int s = 0; s < KS; ++s) {
         const int base = ((KC & 1) && s == KS - 1) ? kaddr_last : kaddr;
         const int lo = ((2 * s) & (SPAN - 1)) << 4, hi = ((2 * s) & ~(SPAN - 1)) << 4;
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + ((base ^ lo) + hi + kb * 32 * KC * 16));
+        const char* ka = Ks + ((base ^ lo) + hi + kb * 32 * KC * 16);
+        if (QPAD && s == KS - 1) ka = hh ? smem + ones_addr : ka;
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ka);
         dst[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], dst[kb], 0, 0, 0);
       }
     }
@@ -837,7 +856,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_sp_kernel(AttnP p, unsigned
         const int i = g - NPV, kb = i / KS, s = i - kb * KS;
         const int base = ((KC & 1) && s == KS - 1) ? kaddr_last : kaddr;
         const int lo = ((2 * s) & (SPAN - 1)) << 4, hi = ((2 * s) & ~(SPAN - 1)) << 4;
-        fr[g] = *reinterpret_cast<const bf16x8*>(Ks + ((base ^ lo) + hi + kb * 32 * KC * 16));
+        const char* ka = Ks + ((base ^ lo) + hi + kb * 32 * KC * 16);
+        if (QPAD && s == KS - 1) ka = hh ? smem + ones_addr : ka;
+        fr[g] = *reinterpret_cast<const bf16x8*>(ka);
       }
     };
 #pragma unroll
@@ -853,13 +874,38 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_sp_kernel(AttnP p, unsigned
         mx = fmaxf(fmaxf(mx, sc[kb][e0 + 4]), sc[kb][e0 + 5]);
         mx = fmaxf(fmaxf(mx, sc[kb][e0 + 6]), sc[kb][e0 + 7]);
       } else if (it == 4) {
-        mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;
-        m_new = fmaxf(m_run, mx);
-        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        if constexpr (QPAD) {
+          mx = fmaxf(mx, __shfl_xor(mx, 32));  // already in exp2 units relative to m_ref
+          const bool move = !PV || mx > QPAD_T;  // !PV: the first tile sets the reference
+          if (__any(move)) {                    // wave-uniform, rare after the first tiles
+            const float ref_new = move ? (float)(bf16)(m_ref + mx) : m_ref;
+            const float delta = ref_new - m_ref;  // exact: difference of two bf16 values
+            m_ref = ref_new;
+            alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) sc[kb][e] -= delta;
+            // the shift of every LATER tile (its last k-step has not been issued yet in this iteration): Q channel Dh, upper half-wave
+            const bf16 nr = (bf16)(-ref_new);
+            qf[KS - 1][0] = hh ? nr : qf[KS - 1][0];
+          }
+        } else {
+          mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;
+          m_new = fmaxf(m_run, mx);
+          alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+          m_run = m_new;
+        }
       } else {
         const int j = it - 5, kb = j >> 3, e = 2 * (j & 7);
-        const float x0 = __builtin_fmaf(sc[kb][e], p.scale_log2, -m_new), x1 = __builtin_fmaf(sc[kb][e + 1], p.scale_log2, -m_new);
+        float x0, x1;
+        if constexpr (QPAD) {
+          x0 = sc[kb][e];
+          x1 = sc[kb][e + 1];
+        } else {
+          x0 = __builtin_fmaf(sc[kb][e], p.scale_log2, -m_new);
+          x1 = __builtin_fmaf(sc[kb][e + 1], p.scale_log2, -m_new);
+        }
         const float p0 = __builtin_amdgcn_exp2f(x0), p1 = __builtin_amdgcn_exp2f(x1);
         if (!ONES) rs += p0 + p1;
         pf[C][kb][e >> 3][e & 7] = (bf16)p0;
@@ -989,8 +1035,9 @@ static int attention_entry(crg_ctx* ctx, void* stream, const void* q, int64_t ld
   static const int use_dma = getenv("CRG_ATTN_DMA") ? atoi(getenv("CRG_ATTN_DMA")) : 1;
   if (use_dma && !vrm && Nk % 64 == 0 && ((long)Nk * ldk * 2 < (1l << 31)) && ((long)Dh * ldv * 2 < (1l << 31))) {
     const bool sp = use_dma == 1 && Nk % 128 == 0;
+    static const int use_occ4 = getenv("CRG_ATTN_OCC4") ? atoi(getenv("CRG_ATTN_OCC4")) : 1;
     if (Dh == 40) {
-      if (sp) return launch_attn_sp<5, 2, 8, 2>(ctx, st, p);
+      if (sp) return use_occ4 ? launch_attn_sp<5, 2, 8, 4>(ctx, st, p) : launch_attn_sp<5, 2, 8, 2>(ctx, st, p);
       return use_dma == 4 ? launch_attn_dma<5, 2, 4, 1, 4>(ctx, st, p) : launch_attn_dma<5, 2, 4, 1, 8>(ctx, st, p);
     }
     if (Dh == 64) {  // measured (B4 N4096 h10: register-staged 256 us, pipelined 253, LDS-DMA on 8 waves 233, on 4 waves 226): plain form, 4 waves
