@@ -42,6 +42,10 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     return rank, world, local
 
 
+_DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2, torch.float64: 3, torch.int64: 4, torch.int32: 5, torch.uint8: 6,
+               torch.bool: 7}
+
+
 def shard_range(n_items: int, rank: int, world: int) -> range:
     """Contiguous, balanced shard of `n_items` independent units (first `n_items % world` ranks get one more)."""
     base, rem = divmod(n_items, world)
@@ -61,6 +65,20 @@ def broadcast_parameters_(tensors: Iterable[torch.Tensor], src: int = 0, group=N
     buckets = {}
     for t in tensors:
         buckets.setdefault((t.dtype, t.device), []).append(t)
+    # header first: every rank must be about to receive exactly what `src` sends (same buckets, in the same order, same sizes) - a
+    # model built differently on one rank otherwise makes the flat broadcast hang or scatter bytes into the wrong parameters
+    dev = next(iter(buckets))[1] if buckets else torch.device("cpu")
+    mine = [len(buckets)] + [v for (dt, _d), ts in buckets.items() for v in (_DTYPE_CODE.get(dt, -1), len(ts), sum(t.numel() for t in ts))]
+    n = torch.tensor([len(mine)], dtype=torch.int64, device=dev)
+    dist.broadcast(n, src=src, group=group)
+    head = torch.tensor(mine if len(mine) == int(n.item()) else [0] * int(n.item()), dtype=torch.int64, device=dev)
+    theirs = head.clone()
+    dist.broadcast(theirs, src=src, group=group)
+    ok = torch.tensor([int(len(mine) == int(n.item()) and bool((theirs == head).all().item()))], dtype=torch.int64, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)  # every rank learns the verdict, so every rank raises (nobody waits alone)
+    if int(ok.item()) != 1:
+        raise RuntimeError(f"broadcast_parameters_: rank {dist.get_rank(group)} holds {mine} (bucket count, then dtype code / tensors / "
+                           f"elements per bucket) which does not match rank {src} on every rank: the models were built differently")
     total = 0
     for (_dt, _dev), ts in buckets.items():
         flat = torch.cat([t.detach().reshape(-1) for t in ts])

@@ -51,7 +51,14 @@ def _need_cuda(*ts):
 
 
 def _h(t: torch.Tensor):
-    return L.ctx(t.device.index if t.device.index is not None else torch.cuda.current_device())
+    """crg context of the tensor's device.  Launches go to torch's CURRENT stream (`_st`), which belongs to the current device: a
+    tensor on another device would have its pointers handed to the wrong GPU's queue, so that is an error, not a silent launch
+    (multi-GPU runs are one process per GPU; a process driving several sets `torch.cuda.device(t.device)` around its calls)."""
+    cur = torch.cuda.current_device()
+    idx = t.device.index if t.device.index is not None else cur
+    if idx != cur:
+        raise L.CrgError(f"tensor lives on cuda:{idx} but the current device is cuda:{cur}: wrap the call in torch.cuda.device(...)")
+    return L.ctx(idx)
 
 
 def _st():

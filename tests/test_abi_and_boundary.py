@@ -173,3 +173,24 @@ def test_reference_side_container_proof():
     # SD1.5 container keys = model.diffusion_model.* + first_stage_model.* (+ the schedule buffers of LatentDiffusion itself)
     n_model = len(unet.state_dict()) + len(vae.state_dict())
     assert 0 < rec["sd15"]["n_keys_hip"] - n_model < 40, (rec["sd15"]["n_keys_hip"], n_model)
+
+
+def test_weight_cache_sees_versioned_writes_only():
+    """pins the rule INTEGRATION.md states: the packed-weight cache is stamped with the Parameter's `_version`, so
+    `p.copy_()` / `p.mul_()` / a fresh Parameter invalidate an entry, while a write through the `.data` alias does not (it bumps
+    the alias's counter) and needs `ops.clear_weight_cache()`."""
+    import torch
+    from cremage_amd import ops
+    cache = ops.TensorKeyedCache()
+    p = torch.nn.Parameter(torch.zeros(4))
+    cache.put((p,), "k", "packed-0")
+    assert cache.get((p,), "k") == "packed-0"
+    p.data.mul_(2.0)                       # invisible: the documented blind spot
+    assert cache.get((p,), "k") == "packed-0"
+    with torch.no_grad():
+        p.copy_(torch.ones(4))             # visible: _version bump
+    assert cache.get((p,), "k") is None
+    cache.put((p,), "k", "packed-1")
+    q = torch.nn.Parameter(torch.ones(4))  # LoRA-style replacement: another object
+    assert cache.get((q,), "k") is None
+    ops.clear_weight_cache()               # the public reset exists and is callable without a GPU

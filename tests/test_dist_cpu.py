@@ -65,6 +65,37 @@ def test_gloo_world2_broadcast_shard_gather():
     assert res[0][5] == res[1][5] == 2.0
 
 
+def _worker_mismatch(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from cremage_amd import dist as D
+    D.init_from_env(backend="gloo")
+    m = torch.nn.Linear(8, 16 if rank == 0 else 12)  # rank 1 built a different model
+    try:
+        D.broadcast_module_(m, src=0)
+        q.put((rank, "no error"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_world2_broadcast_of_mismatched_models_fails_on_every_rank():
+    """the header check of broadcast_parameters_: a rank whose buckets differ from the source's makes EVERY rank raise (no hang, no bytes
+    scattered into the wrong parameters)"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mismatch, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all("built differently" in res[r] for r in range(world)), res
+
+
 def test_shard_range_partitions_everything():
     from cremage_amd import dist as D
     for n in [0, 1, 7, 16, 33]:
