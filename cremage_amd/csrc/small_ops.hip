@@ -7,10 +7,11 @@ namespace {
 template <typename T>
 __device__ __forceinline__ float ldf(const T* p) { return (float)*p; }
 
-// ---- conv (3x3 or 1x1), Cin <= 8 (conv_in): thread = (pixel, 8 output channels); weights in LDS as
-// [tap*Cin + ci][Cout] fp32; the whole input pixel (<= 8 channels) is one vector load per tap and the 8 outputs
-// one 16-byte store.
-template <typename XT, typename YT, int CI>
+// ---- conv (3x3 or 1x1), Cin <= 8 (conv_in): thread = (PX consecutive pixels of one image row, 8 output channels); weights in
+// LDS as [tap*Cin + ci][Cout] fp32; the whole input pixel (<= 8 channels) is one vector load per tap and the 8 outputs one
+// 16-byte store.  The kernel is LDS-read bound (two 16-byte weight reads per (tap, ci) against 8 FMAs per pixel): PX = 4 pixels share
+// every weight read (conv_in 4 -> 320 at 8 x 64 x 64: 65 -> see DESIGN us); widths that are not a multiple of 4 run PX = 1.
+template <typename XT, typename YT, int CI, int PX>
 __global__ __launch_bounds__(256) void conv_small_cin_kernel(const XT* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, YT* __restrict__ y, int N, int H, int W,
                                                              int Cout, int ks) {
@@ -23,48 +24,61 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const XT* __restric
   }
   __syncthreads();
   const int cg = Cout >> 3;  // 8-channel groups
-  const long total = (long)N * H * W * cg;
+  const int WQ = W / PX;
+  const long total = (long)N * H * WQ * cg;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int g = (int)(idx % cg);
-    const long pix = idx / cg;
-    const int wo = (int)(pix % W);
-    const int ho = (int)((pix / W) % H);
-    const int n = (int)(pix / ((long)W * H));
-    float acc[8];
+    const long pq = idx / cg;
+    const int wo0 = (int)(pq % WQ) * PX;
+    const int ho = (int)((pq / WQ) % H);
+    const int n = (int)(pq / ((long)WQ * H));
+    float acc[PX][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[g * 8 + e] : 0.f;
+    for (int px = 0; px < PX; ++px)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[px][e] = bias ? bias[g * 8 + e] : 0.f;
     for (int tap = 0; tap < taps; ++tap) {
-      const int hi = ho + tap / ks - pad, wi = wo + tap % ks - pad;
-      if ((unsigned)hi >= (unsigned)H || (unsigned)wi >= (unsigned)W) continue;
-      const XT* xp = x + (((long)n * H + hi) * W + wi) * CI;
-      float xv[CI];
-      if constexpr (CI == 4 && sizeof(XT) == 2) {
-        const bf16x4 v = *reinterpret_cast<const bf16x4*>(xp);
+      const int hi = ho + tap / ks - pad;
+      if ((unsigned)hi >= (unsigned)H) continue;
+      float xv[PX][CI];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) xv[c] = (float)v[c];
-      } else if constexpr (CI == 4 && sizeof(XT) == 4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xp);
+      for (int px = 0; px < PX; ++px) {
+        const int wi = wo0 + px + tap % ks - pad;
+        const bool ok = (unsigned)wi < (unsigned)W;
+        const XT* xp = x + (((long)n * H + hi) * W + (ok ? wi : 0)) * CI;
+        if constexpr (CI == 4 && sizeof(XT) == 2) {
+          const bf16x4 v = *reinterpret_cast<const bf16x4*>(xp);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) xv[c] = v[c];
-      } else {
+          for (int c = 0; c < 4; ++c) xv[px][c] = ok ? (float)v[c] : 0.f;
+        } else if constexpr (CI == 4 && sizeof(XT) == 4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xp);
 #pragma unroll
-        for (int c = 0; c < CI; ++c) xv[c] = (float)xp[c];
+          for (int c = 0; c < 4; ++c) xv[px][c] = ok ? v[c] : 0.f;
+        } else {
+#pragma unroll
+          for (int c = 0; c < CI; ++c) xv[px][c] = ok ? (float)xp[c] : 0.f;
+        }
       }
 #pragma unroll
       for (int ci = 0; ci < CI; ++ci) {
         const float* wp = wl + (tap * CI + ci) * Cout + g * 8;
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc[e] += xv[ci] * w0[e];
-          acc[4 + e] += xv[ci] * w1[e];
-        }
+        for (int px = 0; px < PX; ++px)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[px][e] += xv[px][ci] * w0[e];
+            acc[px][4 + e] += xv[px][ci] * w1[e];
+          }
       }
     }
-    crg_vec8<YT> o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o.set(e, acc[e]);
-    o.store(y + pix * Cout + g * 8);
+    for (int px = 0; px < PX; ++px) {
+      crg_vec8<YT> o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.set(e, acc[px][e]);
+      o.store(y + (((long)n * H + ho) * W + wo0 + px) * Cout + g * 8);
+    }
   }
 }
 
@@ -258,14 +272,15 @@ extern "C" int crg_conv_small(crg_ctx* ctx, void* stream, const void* x, const f
     rc = by_dtype2(ctx, x_dtype, y_dtype, "conv_small", [&](auto* xs, auto* ys) {
       using XT = std::remove_const_t<std::remove_pointer_t<decltype(xs)>>;
       using YT = std::remove_pointer_t<decltype(ys)>;
-      const dim3 grid(grid_resident((long)N * H * W * (Cout / 8), lds));
+      const bool quad = W % 4 == 0 && Cin <= 4;  // 4 pixels per thread (8-channel inputs would need 32 more registers: one pixel)
+      const dim3 grid(grid_resident((long)N * H * (quad ? W / 4 : W) * (Cout / 8), lds));
       auto go = [&](auto kern) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cout, ks);
       };
-      if (Cin == 3) go(conv_small_cin_kernel<XT, YT, 3>);
-      else if (Cin == 4) go(conv_small_cin_kernel<XT, YT, 4>);
-      else go(conv_small_cin_kernel<XT, YT, 8>);
+      if (Cin == 3) quad ? go(conv_small_cin_kernel<XT, YT, 3, 4>) : go(conv_small_cin_kernel<XT, YT, 3, 1>);
+      else if (Cin == 4) quad ? go(conv_small_cin_kernel<XT, YT, 4, 4>) : go(conv_small_cin_kernel<XT, YT, 4, 1>);
+      else go(conv_small_cin_kernel<XT, YT, 8, 1>);
       return 0;
     });
   }

@@ -371,6 +371,17 @@ def test_conv_unet_shapes(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ci,co,ks,h,w", [(4, 320, 3, 6, 12), (3, 128, 3, 5, 8), (4, 64, 1, 3, 4), (4, 320, 3, 64, 64)])
+def test_conv_small_four_pixels_per_thread(dtype, ci, co, ks, h, w):
+    """conv_in form with W % 4 == 0: four pixels of a row share every weight read (borders inside a quad, the production 64x64 shape)"""
+    from cremage_amd import ops
+    x, wt, b = rnd(2, ci, h, w, seed=43), rnd(co, ci, ks, ks, seed=44, scale=(ci * ks * ks) ** -0.5), rnd(co, seed=45)
+    ref = F.conv2d(q(x, dtype), wt, b, padding=ks // 2)
+    got = ops.conv2d(nhwc(x, dtype), wt.to(_dev()), b.to(_dev()), padding=ks // 2)
+    check(got, ref, dtype, f"conv_small quad {ci}->{co} k{ks} {h}x{w}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ci,co,ks", [(4, 64, 3), (4, 320, 3), (3, 128, 3), (320, 4, 3), (128, 3, 3), (64, 8, 3), (8, 8, 1), (4, 4, 1)])
 def test_conv_small(dtype, ci, co, ks):
     from cremage_amd import ops
