@@ -13,6 +13,7 @@
 // stores) runs while the next n-tile's weights are already landing.  X is read once, LN(X) never leaves the chip.
 // 8 waves = 4 (m) x 2 (n), wave tile 32 x 16*WNT; LDS = 16 KB * K/64 + 4 * BN * 128 B (160 KB at K = 320, BN = 160).
 #include "gemm_shared.h"
+#include <stdlib.h>
 
 namespace crg_mm {
 
@@ -150,11 +151,15 @@ template <int EXTRA>
 static __device__ __forceinline__ void ln_wait_nw(int nW) {
   if (nW == 2) wait_vmcnt<2 + EXTRA>();
   else if (nW == 3) wait_vmcnt<3 + EXTRA>();
+  else if (nW == 4) wait_vmcnt<4 + EXTRA>();
   else if (nW == 1) wait_vmcnt<1 + EXTRA>();
   else ln_wait(nW + EXTRA);
 }
 
-template <int WNT, int KT, bool GEGLU>
+// ALIAS: the weight ring lies OVER the resident rows (they are only needed until every wave holds its activation fragments in
+// registers), which makes room for 256-column n-tiles (four 32 KB slots = 128 KB): half the barriers and a third fewer fragment
+// reads per FLOP.  K-tile u then lives in slot (u + 3) & 3, so that k-tile 0 can land (slot 3, beyond the rows) during the prologue.
+template <int WNT, int KT, bool GEGLU, bool ALIAS = false>
 __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
   constexpr bool PAIR = !GEGLU;  // plain outputs use the paired column mapping (16-byte stores); GEGLU its own [v16 | g16] packing
   constexpr int WMT = 2, NW = 8, BMR = 128, WST = 4;
@@ -168,7 +173,9 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
   constexpr int OOB = (int)0x80000000;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Ares = smem;                  // [KT][128][128 B], chunk XOR-swizzled by (row & 7)
-  char* const wring = smem + KT * A_KT;     // [WST][BN x 128 B]
+  char* const wring = ALIAS ? smem : smem + KT * A_KT;  // [WST][BN x 128 B]
+  static_assert(!ALIAS || 3 * WS_BYTES >= KT * A_KT, "slot 3 must lie beyond the resident rows");
+  constexpr int SROT = ALIAS ? 3 : 0;       // k-tile u -> ring slot (u + SROT) & 3
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
   }
   auto stage_w = [&](int u) {  // weight k-tile u = (n-tile u / KT, k-tile u % KT) into ring slot u & 3
     const int nt = u / KT, kt = u - nt * KT;
-    char* ws = wring + (u & 3) * WS_BYTES;
+    char* ws = wring + ((u + SROT) & 3) * WS_BYTES;
     const int soff = (int)((long)nt * BN * p.ldw * 2) + kt * 128;  // rows past N fall beyond w_bytes: zero-filled
 #pragma unroll
     for (int q = 0; q < WL; ++q)
@@ -211,8 +218,10 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
   // (weight k-tiles past the last one: their rows lie beyond w_bytes, the DMA writes zeros into slots nobody reads - issuing them
   // anyway keeps every wait of the loop at its steady-state count and every fragment read unconditional)
   stage_w(0);
-  stage_w(1);
-  stage_w(2);
+  if (!ALIAS) {
+    stage_w(1);
+    stage_w(2);
+  }
 
   // ---- LayerNorm of the resident rows, in place: wave w owns rows 16 w .. 16 w + 15, 8 lanes per row ----
   // (gamma == null: no LayerNorm - the kernel is then a plain row-resident GEMM for K = 320)
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
     }
     // the rows (older than the three weight batches) have landed once at most 3 nW operations of this wave are outstanding;
     // the gamma / beta loads above are younger still, the compiler waits for them itself at their first use
-    ln_wait(nW * 3);
+    ln_wait(nW * (ALIAS ? 1 : 3));
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -287,11 +296,11 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
 
   // fragment sets: F0 = first 32-wide k-step of the CURRENT k-tile (requested during the previous k-tile, whose barrier already
   // made this k-tile's weights visible), F1 = its second k-step (requested at the top, consumed after F0's MFMAs)
-  bf16x8 xf0[WMT], wf0[WNT], xf1[WMT], wf1[WNT];
-  auto read_frags = [&](bf16x8 (&xf)[WMT], bf16x8 (&wf)[WNT], int kt, int slot, int ks) {
-    const char* as = Ares + kt * A_KT;
-#pragma unroll
-    for (int j = 0; j < WMT; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(as + (aoff[j] ^ (ks << 6)));
+  // The wave's activation fragments stay in REGISTERS for the whole kernel (KT x 2 k-steps x WMT fragments = 80 VGPRs at K = 320):
+  // they are the same for every n-tile, and reading them from LDS in every k-tile was a third of the loop's ds_read_b128s.
+  bf16x8 xa[KT][2][WMT];
+  bf16x8 wf0[WNT], wf1[WNT];
+  auto read_frags = [&](bf16x8 (&wf)[WNT], int slot, int ks) {
     const char* wbase = wring + slot * WS_BYTES + (wb0 ^ (ks << 6));
 #pragma unroll
     for (int i = 0; i < WNT; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wbase + i * 2048);
@@ -302,13 +311,43 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
 #pragma unroll
       for (int j = 0; j < WMT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
   };
-  {
+  if constexpr (ALIAS) {
+    // rows landed (no LayerNorm: nobody waited yet), normalised rows published -> fragments into registers -> the rows' LDS becomes
+    // ring slots 0 .. 2: only now may k-tiles 1 and 2 be requested
+    ln_wait(nW);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < WMT; ++j) xa[kt][ks][j] = *reinterpret_cast<const bf16x8*>(Ares + kt * A_KT + (aoff[j] ^ (ks << 6)));
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the fragments are in registers
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stage_w(1);
+    stage_w(2);
+    ln_wait(nW * 2);  // k-tile 0 (requested first) landed
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(wf0, SROT, 0);
+  } else {
     // weight k-tile 0 landed (two batches may stay in flight); this barrier also publishes the normalised rows
     ln_wait(nW * 2);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    read_frags(xf0, wf0, 0, 0, 0);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < WMT; ++j) xa[kt][ks][j] = *reinterpret_cast<const bf16x8*>(Ares + kt * A_KT + (aoff[j] ^ (ks << 6)));
+    read_frags(wf0, 0, 0);
   }
   for (int nt = 0; nt < tiles_n; ++nt) {
     const int n0 = nt * BN;
@@ -321,8 +360,12 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
       // ... and the NST stores of the previous n-tile's epilogue, issued between the batches of k-tiles u_e + 3 and u_e + 4
       // (u_e = that n-tile's last k-tile), are younger than what the first two waits of an n-tile need: they stay in flight too
       if (kt < 2 && nt > 0) {
-        if (!GEGLU && p.vt && (nt - 1) * BN >= p.vt_n0) ln_wait_nw<NSTT>(nW);
-        else ln_wait_nw<NST>(nW);
+        bool transposed_prev = false;
+        if constexpr (!GEGLU) {
+          transposed_prev = p.vt && (nt - 1) * BN >= p.vt_n0;
+          if (transposed_prev) ln_wait_nw<NSTT>(nW);
+        }
+        if (!transposed_prev) ln_wait_nw<NST>(nW);
       } else {
         ln_wait_nw<0>(nW);
       }
@@ -332,10 +375,10 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
       // (ablation builds -DCRG_LN_ABL_NOMMA / -DCRG_LN_ABL_NODMA, N = 2560 GEGLU: 87 us full, 82 without the DMA, 66 without the
       // MFMAs, 53 without either: barrier + fragment reads + prologue / epilogue are the larger part.  Running the two waves of a
       // SIMD in opposite orders - w + 4 issues its first MFMA block before its fragment reads - measured 88 -> 91 us, not kept.)
-      read_frags(xf1, wf1, kt, u & 3, 1);
+      read_frags(wf1, (u + SROT) & 3, 1);
       __builtin_amdgcn_sched_barrier(0);
 #ifndef CRG_LN_ABL_NOMMA
-      mma(xf0, wf0);
+      mma(xa[kt][0], wf0);
 #endif
       __builtin_amdgcn_sched_barrier(0);
 #ifndef CRG_LN_ABL_NODMA
@@ -343,12 +386,12 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
 #endif
       // unconditional (after the last k-tile it reads a slot of zeros): behind a branch the compiler cannot count these reads and
       // makes the MFMAs below wait for lgkmcnt(0), i.e. for the prefetch as well as for their own operands
-      read_frags(xf0, wf0, kt + 1 < KT ? kt + 1 : 0, (u + 1) & 3, 0);
+      read_frags(wf0, (u + 1 + SROT) & 3, 0);
       __builtin_amdgcn_sched_barrier(0);
 #ifndef CRG_LN_ABL_NOMMA
-      mma(xf1, wf1);
+      mma(xa[kt][1], wf1);
 #else
-      asm volatile("" ::"v"(xf1[0]), "v"(wf1[0]), "v"(xf0[0]), "v"(wf0[0]));
+      asm volatile("" ::"v"(wf1[0]), "v"(wf0[0]));
 #endif
     }
     // ---- epilogue of n-tile nt (the ring keeps filling underneath): exactly NST store instructions per wave ----
@@ -520,12 +563,15 @@ extern "C" int crg_ln_gemm(crg_ctx* ctx, void* stream, const crg_lngemm_args* a)
   hipStream_t st = (hipStream_t)stream;
   void (*kern)(LnGemmP);
   int bn;
-  if (geglu) { kern = lngemm_kernel<4, 5, true>; bn = 128; }
+  static const int use_alias = getenv("CRG_LN_WIDE") ? atoi(getenv("CRG_LN_WIDE")) : 1;  // dev knob: 0 = 128-column GEGLU tiles
+  const bool alias = geglu && use_alias && a->N % 256 == 0;
+  if (alias) { kern = lngemm_kernel<8, 5, true, true>; bn = 256; }
+  else if (geglu) { kern = lngemm_kernel<4, 5, true>; bn = 128; }
   else if (wide) { kern = lngemm_kernel<5, 5, false>; bn = 160; }
   else { kern = lngemm_kernel<4, 5, false>; bn = 128; }
-  const size_t lds = (size_t)5 * 128 * 128 + (size_t)4 * bn * 128;
-  static bool attr_set[3] = {};
-  const int ai = geglu ? 0 : (wide ? 1 : 2);
+  const size_t lds = alias ? (size_t)4 * bn * 128 : (size_t)5 * 128 * 128 + (size_t)4 * bn * 128;
+  static bool attr_set[4] = {};
+  const int ai = alias ? 3 : (geglu ? 0 : (wide ? 1 : 2));
   if (!attr_set[ai]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return crg_fail(ctx, -5, "ln_gemm: cannot set dynamic LDS: %s", hipGetErrorString(e));

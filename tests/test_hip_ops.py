@@ -97,10 +97,12 @@ def test_geglu(dtype, M, C):
 
 
 @pytest.mark.parametrize("M,N,act,bias", [(300, 960, None, False), (1024, 320, None, False), (4096, 2560, "geglu", True), (128, 336, None, True),
-                                          (77, 400, None, True), (2, 640, "geglu", True), (32768, 960, None, False)])
+                                          (77, 400, None, True), (2, 640, "geglu", True), (32768, 960, None, False), (300, 512, "geglu", True),
+                                          (1000, 2560, "geglu", False)])
 def test_ln_linear(M, N, act, bias):
     """crg_ln_gemm (LayerNorm fused into the consuming GEMM, K = 320; lngemm.hip) against LayerNorm -> bf16 rounding -> Linear:
-    row tails (M % 128 != 0), 160- and 128-wide tiles, the paired and the plain column mapping, bias, GEGLU, and bitwise
+    row tails (M % 128 != 0), 160- and 128-wide tiles, the 256-wide GEGLU tiles whose weight ring overlays the resident rows
+    (N % 256 == 0), the paired and the plain column mapping, bias, GEGLU, and bitwise
     agreement of the normalised operand with the stand-alone crg_layernorm (same two-pass arithmetic)."""
     from cremage_amd import ops
     K = 320
