@@ -59,6 +59,9 @@ static __device__ __forceinline__ void ln_store8(void* base, unsigned bytes, int
   const auto rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
   u32x2 r;
   __builtin_memcpy(&r, &v, 8);
+#ifdef CRG_LN_ABL_NOSTORE  // timing ablation only: every 8-byte store goes out of range (dropped by the range check, still counted in vmcnt)
+  voff = (int)0x80000000;
+#endif
   __builtin_amdgcn_raw_buffer_store_b64(r, rs, voff, 0, 0);
 #endif
 }
