@@ -57,7 +57,7 @@ def slot_of(name):
         return "lngemm"
     if "gemm_kernel" in name:
         return "conv_x3" if (("Lb1E" in name) or re.search(r", true[,>]", name)) else "gemm_x3"
-    for pat, slot in (("splitk_reduce", "splitk_reduce"), ("attn_kernel", "attention"), ("gn_stats", "gn_stats"), ("gn_apply", "gn_apply"), ("gn_small", "gn_apply"),
+    for pat, slot in (("splitk_reduce", "splitk_reduce"), ("attn_kernel", "attention"), ("attn_sp_kernel", "attention"), ("attn_dma_kernel", "attention"), ("gn_stats", "gn_stats"), ("gn_apply", "gn_apply"), ("gn_small", "gn_apply"),
                       ("layernorm_kernel", "layernorm"), ("softmax_rows", "softmax"), ("conv_small", "conv_small")):
         if pat in name:
             return slot
