@@ -687,8 +687,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_sp_kernel(AttnP p, unsigned
   constexpr int NQ = (NI + NW - 1) / NW;
   constexpr int Dh = KC * 8;
   // Dh = 8 (mod 16): the last k-step of Q K^T has eight padded channels.  They carry the softmax's shift: Q is pre-multiplied by
-  // scale * log2(e) when its fragments are loaded and its channel Dh holds -m_ref, K's channels Dh.. read a chunk of ones, so the MFMA
-  // delivers s * scale * log2(e) - m_ref and P = exp2 of it directly - no v_fma per score.  m_ref (per query, bf16-exact) follows the
+  // scale * log2(e) when its fragments are loaded and its channels Dh, Dh + 1 hold -m_ref (as hi + lo), K's channels Dh.. read a chunk of ones, so the MFMA
+  // delivers s * scale * log2(e) - m_ref and P = exp2 of it directly - no v_fma per score.  m_ref (per query, exactly hi + lo) follows the
   // row maximum lazily: it moves only when a tile's maximum exceeds it by more than QPAD_T (P then stays below 2^QPAD_T), which
   // costs that tile one subtraction per score and the accumulators one rescale; always on the first tile.
 #ifdef CRG_ATTN_NO_QPAD
@@ -878,17 +878,25 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_sp_kernel(AttnP p, unsigned
           mx = fmaxf(mx, __shfl_xor(mx, 32));  // already in exp2 units relative to m_ref
           const bool move = !PV || mx > QPAD_T;  // !PV: the first tile sets the reference
           if (__any(move)) {                    // wave-uniform, rare after the first tiles
-            const float ref_new = move ? (float)(bf16)(m_ref + mx) : m_ref;
-            const float delta = ref_new - m_ref;  // exact: difference of two bf16 values
+            // the new reference as TWO bf16 values (channels Dh and Dh + 1: hi + lo, 16 significant bits): with one, its rounding
+            // error (2^-9 of a large logit) could put the tile's maximum far above or below zero
+            const float want = m_ref + mx;
+            const bf16 r_hi = (bf16)want;
+            const bf16 r_lo = (bf16)(want - (float)r_hi);
+            const float ref_new = move ? (float)r_hi + (float)r_lo : m_ref;  // exact in fp32
+            const float delta = ref_new - m_ref;
             m_ref = ref_new;
             alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
               for (int e = 0; e < 16; ++e) sc[kb][e] -= delta;
-            // the shift of every LATER tile (its last k-step has not been issued yet in this iteration): Q channel Dh, upper half-wave
-            const bf16 nr = (bf16)(-ref_new);
-            qf[KS - 1][0] = hh ? nr : qf[KS - 1][0];
+            // the shift of every LATER tile (its last k-step has not been issued yet in this iteration): Q channels Dh, Dh + 1 of the
+            // upper half-wave, against the ones chunk of K
+            if (move && hh) {
+              qf[KS - 1][0] = (bf16)(-(float)r_hi);
+              qf[KS - 1][1] = (bf16)(-(float)r_lo);
+            }
           }
         } else {
           mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;
