@@ -512,7 +512,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_dma_kernel(AttnP p, unsigne
     vaddr[dv] = KBYTES + lrow * 128 + ((((lrow >> 1) & 7) ^ hh) << 4);
   }
 
-  const int nsuper = p.Nk / (64 * SUB);
+  const int nsuper = (p.Nk + 64 * SUB - 1) / (64 * SUB);  // a key tail (Nk % 64, SUB == 1 only) is masked in the last tile below
 #ifdef CRG_ATTN_LAPS
   unsigned long long lap[5] = {0, 0, 0, 0, 0}, tl = wall_clock64();
   const unsigned long long mt0 = __builtin_amdgcn_s_memtime(), rt0 = tl;
@@ -523,6 +523,24 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_dma_kernel(AttnP p, unsigne
   for (int super = 0; super < nsuper; ++super) {
     LAP(4);
     if (super + 1 < nsuper) issue(super + 1, (super + 1) & 1);
+    if (SUB == 1 && super + 1 == nsuper && (p.Nk & 63)) {
+      // key tail: the V^T chunks were copied raw, so the columns Nk .. of the last tile hold the producer's row padding or the next
+      // channel's keys; P is 0 there, but 0 x NaN is not - zero them in LDS (block-uniform branch, last tile only)
+      char* Vs = smem + (super & 1) * TSTAGE + KBYTES;
+      for (int i = t; i < Dh * 8; i += 64 * NW) {
+        const int d = i >> 3, cpos = i & 7;
+        const int key0 = super * 64 + (cpos ^ ((d >> 1) & 7)) * 8;
+        if (key0 + 8 > p.Nk) {
+          bf16x8* cp = reinterpret_cast<bf16x8*>(Vs + d * 128 + cpos * 16);
+          bf16x8 v = *cp;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (key0 + e >= p.Nk) v[e] = (bf16)0.f;
+          *cp = v;
+        }
+      }
+      __syncthreads();
+    }
     LAP(0);
 #pragma unroll
     for (int sub = 0; sub < SUB; ++sub) {
@@ -542,6 +560,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_dma_kernel(AttnP p, unsigne
         }
       }
       LAP(1);
+      if (SUB == 1 && super + 1 == nsuper && (p.Nk & 63)) {  // block-uniform: keys past Nk (their K rows were zero-filled) leave the softmax
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            // S^T row rho = 32 kb + (e & 3) + 8 (e >> 2) + 4 hh holds key pi(rho): bits 2 and 3 swapped
+            const int key = super * 64 + kb * 32 + (e & 3) + 4 * ((e >> 2) & 1) + 8 * hh + 16 * (e >> 3);
+            if (key >= p.Nk) st[kb][e] = -INFINITY;
+          }
+      }
       float mx = fmaxf(fmaxf(st[0][0], st[1][0]), st[0][1]);
 #pragma unroll
       for (int e = 1; e < 15; ++e) mx = fmaxf(fmaxf(mx, st[1][e]), st[0][e + 1]);
@@ -662,7 +690,7 @@ template <int KC, int NV, int OCC, int SUB, int NW>
 int launch_attn_dma(crg_ctx* ctx, hipStream_t st, const AttnP& p) {
   dim3 grid((p.Nq + 32 * NW - 1) / (32 * NW), p.B * p.H);
   const unsigned k_bytes = (unsigned)((((long)p.Nk - 1) * p.ldk + p.Dh) * 2);
-  const unsigned v_bytes = (unsigned)((((long)p.Dh - 1) * p.ldvt + p.Nk) * 2);
+  const unsigned v_bytes = (unsigned)((((long)p.Dh - 1) * p.ldvt + (p.Nk + 7) / 8 * 8) * 2);  // whole 16-byte chunks (ldvt >= roundup(Nk, 8))
   hipLaunchKernelGGL((attn_dma_kernel<KC, NV, (KC * 8 < NV * 32), OCC, SUB, NW>), grid, dim3(64 * NW), 0, st, p, k_bytes, v_bytes);
   CRG_CHECK_LAUNCH(ctx, "attention (LDS-DMA)");
   return 0;
@@ -998,7 +1026,7 @@ template <int KC, int NV, int NW, int OCC>
 int launch_attn_sp(crg_ctx* ctx, hipStream_t st, const AttnP& p) {
   dim3 grid((p.Nq + 32 * NW - 1) / (32 * NW), p.B * p.H);
   const unsigned k_bytes = (unsigned)((((long)p.Nk - 1) * p.ldk + p.Dh) * 2);
-  const unsigned v_bytes = (unsigned)((((long)p.Dh - 1) * p.ldvt + p.Nk) * 2);
+  const unsigned v_bytes = (unsigned)((((long)p.Dh - 1) * p.ldvt + (p.Nk + 7) / 8 * 8) * 2);  // whole 16-byte chunks (ldvt >= roundup(Nk, 8))
   hipLaunchKernelGGL((attn_sp_kernel<KC, NV, (KC * 8 < NV * 32), NW, OCC>), grid, dim3(64 * NW), 0, st, p, k_bytes, v_bytes);
   CRG_CHECK_LAUNCH(ctx, "attention (software-pipelined)");
   return 0;
@@ -1041,12 +1069,14 @@ static int attention_entry(crg_ctx* ctx, void* stream, const void* q, int64_t ld
   // CRG_ATTN_DMA (developer knob): 0 = register-staged kernel only, 1 (default) = software-pipelined where instantiated, else the
   // plain LDS-DMA kernel, 8 / 4 = plain LDS-DMA kernel on 8 / 4 waves
   static const int use_dma = getenv("CRG_ATTN_DMA") ? atoi(getenv("CRG_ATTN_DMA")) : 1;
-  if (use_dma && !vrm && Nk % 64 == 0 && ((long)Nk * ldk * 2 < (1l << 31)) && ((long)Dh * ldv * 2 < (1l << 31))) {
+  static const int dma_tail = getenv("CRG_ATTN_TAIL") ? atoi(getenv("CRG_ATTN_TAIL")) : 1;  // key tails on the LDS-DMA kernel (0: register-staged)
+  if (use_dma && !vrm && (Nk % 64 == 0 || (dma_tail && Nk > 8)) && ((long)Nk * ldk * 2 < (1l << 31)) && ((long)Dh * ldv * 2 < (1l << 31))) {
     const bool sp = use_dma == 1 && Nk % 128 == 0;
     static const int use_occ4 = getenv("CRG_ATTN_OCC4") ? atoi(getenv("CRG_ATTN_OCC4")) : 1;
     if (Dh == 40) {
       if (sp) return use_occ4 ? launch_attn_sp<5, 2, 8, 4>(ctx, st, p) : launch_attn_sp<5, 2, 8, 2>(ctx, st, p);
-      return use_dma == 4 ? launch_attn_dma<5, 2, 4, 1, 4>(ctx, st, p) : launch_attn_dma<5, 2, 4, 1, 8>(ctx, st, p);
+      // few key tiles (cross-attention: 77 keys): 128-query blocks, i.e. twice the blocks and four-wave barriers (19.2 vs 19.9 us)
+      return (use_dma == 4 || (use_dma == 1 && Nk <= 256)) ? launch_attn_dma<5, 2, 4, 1, 4>(ctx, st, p) : launch_attn_dma<5, 2, 4, 1, 8>(ctx, st, p);
     }
     if (Dh == 64) {  // measured (B4 N4096 h10: register-staged 256 us, pipelined 253, LDS-DMA on 8 waves 233, on 4 waves 226): plain form, 4 waves
       if (use_dma == 5 && Nk % 128 == 0) return launch_attn_sp<8, 2, 8, 2>(ctx, st, p);
