@@ -386,6 +386,17 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
 //  * V^T tile [Dh rows][8 chunks] + one all-ones row + one zero row per stage (written once; padded rows of the A operand are
 //    redirected to them): chunk c of row d at position c ^ ((d >> 1) & 7), conflict-free for the same lane groups.
 // Rows past Nk: the buffer descriptor's range check returns zeros.
+// max(v[lane], v[lane ^ 32]) without the LDS crossbar: v_permlane32_swap exchanges the upper half of one register with the lower
+// half of another in one VALU instruction.  (__shfl_xor is a ds_bpermute: its lgkmcnt(0) wait also drains the fragment reads that
+// were issued ahead for the next MFMAs.)
+static __device__ __forceinline__ float attn_max_halves(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#else
+  return v;
+#endif
+}
 typedef __attribute__((address_space(3))) void* lptr_t;
 static __device__ __forceinline__ void attn_dma16(const void* base, unsigned bytes, char* lds, int voff, int soff) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -574,7 +585,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_dma_kernel(AttnP p, unsigne
 #pragma unroll
       for (int e = 1; e < 15; ++e) mx = fmaxf(fmaxf(mx, st[1][e]), st[0][e + 1]);
       mx = fmaxf(mx, st[1][15]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;
+      mx = attn_max_halves(mx) * p.scale_log2;
       const float m_new = fmaxf(m_run, mx);
       if (__any(m_new != m_run)) {  // wave-uniform: rescale only when some row's running max moved
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -903,7 +914,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_sp_kernel(AttnP p, unsigned
         mx = fmaxf(fmaxf(mx, sc[kb][e0 + 6]), sc[kb][e0 + 7]);
       } else if (it == 4) {
         if constexpr (QPAD) {
-          mx = fmaxf(mx, __shfl_xor(mx, 32));  // already in exp2 units relative to m_ref
+          mx = attn_max_halves(mx);  // already in exp2 units relative to m_ref
           const bool move = !PV || mx > QPAD_T;  // !PV: the first tile sets the reference
           if (__any(move)) {                    // wave-uniform, rare after the first tiles
             // the new reference as TWO bf16 values (channels Dh and Dh + 1: hi + lo, 16 significant bits): with one, its rounding
@@ -927,7 +938,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_sp_kernel(AttnP p, unsigned
             }
           }
         } else {
-          mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;
+          mx = attn_max_halves(mx) * p.scale_log2;
           m_new = fmaxf(m_run, mx);
           alpha = __builtin_amdgcn_exp2f(m_run - m_new);
           m_run = m_new;
