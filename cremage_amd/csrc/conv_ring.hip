@@ -54,6 +54,15 @@ static __device__ __forceinline__ void dma16(const void* base, unsigned bytes, c
 #endif
 }
 
+#ifdef CRG_RING_STAMPS
+// dev instrumentation (tools/ring_stamp_probe.py; build with tools/build_variant.sh stamps -DCRG_RING_STAMPS): wall_clock64 stamps of
+// wave 0 of every block: 0 entry, 1 first operands landed (prologue barrier passed), 2 K loop done, 3 epilogue stores issued
+__device__ unsigned long long crg_ring_stamps[1024 * 4];
+#define RING_STAMP(i) do { if (t == 0 && blockIdx.x < 1024) crg_ring_stamps[blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define RING_STAMP(i)
+#endif
+
 template <int WNT, bool PAIR, int SPREAD, bool LIN>
 __global__ __launch_bounds__(512, 2) void conv3_ring_kernel(GemmP p) {
   constexpr int WMT = 4, NW = 8, TP = 256, WST = 4;
@@ -65,6 +74,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ring_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int t = threadIdx.x;
+  RING_STAMP(0);
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -292,6 +302,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ring_kernel(GemmP p) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    RING_STAMP(1);
     set_xoff(0);
     read_x(xf0, xbuf, 0, 0);
     read_w(wf0, wring, 0);
@@ -471,6 +482,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ring_kernel(GemmP p) {
       fetch_res();
     }
   }
+  RING_STAMP(2);
   if (p.splits > 1 && p.inred) {
     // ---- in-launch split-K sum (guide 5, "In-launch split-K reduction"; placement-independent, no spin, no float atomics) ----
     // every slice stores its accumulators as a register image (f32x4 per lane, 1 KiB coalesced wave-stores), drains, and ONE lane
@@ -529,7 +541,16 @@ __global__ __launch_bounds__(512, 2) void conv3_ring_kernel(GemmP p) {
   } else {
     gemm_epilogue<WNT, bf16, WMT>(p, acc, m0, n0, wm, wn, frow, fq, 0, sid, rres, pre_res, bpre, pre_bias);
   }
+  RING_STAMP(3);
 }
+
+#ifdef CRG_RING_STAMPS
+}  // namespace crg_mm
+extern "C" int crg_debug_read_ring(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(crg_mm::crg_ring_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+namespace crg_mm {
+#endif
 
 // Host entry (called from gemm_conv.hip's launch_kernel in place of the 2-stage 256-row kernel): bf16 in / bf16 out.
 int launch_conv_ring(crg_ctx* ctx, hipStream_t st, const GemmP& p, int wnt, int spread) {
