@@ -69,16 +69,7 @@ def main():
 
     # ---- model: rank 0 materialises the synthetic weights, the others receive them over RCCL ----
     t0 = time.time()
-    if rank == 0:
-        ldm = P.build_synthetic_ldm(device=dev, unet_dtype=torch.bfloat16, vae_dtype=torch.float32, seed=1234)
-    else:
-        from cremage_amd.ldm_hip.latent_diffusion import LatentDiffusion
-        from cremage_amd.ldm_hip.unet import UNetModel
-        from cremage_amd.ldm_hip.vae import AutoencoderKL
-        ldm = LatentDiffusion(UNetModel(**P.SD15_UNET), AutoencoderKL(P.SD15_VAE_DD, None, 4))
-        ldm.model.to(torch.bfloat16)
-        ldm = ldm.to(dev).eval()
-    bcast_bytes = D.broadcast_module_(ldm, src=0)
+    ldm, bcast_bytes = P.build_ldm_sharded(rank, dev, unet_dtype=torch.bfloat16, vae_dtype=torch.float32, seed=1234)
     if not a.no_graph:
         ldm.model.enable_hip_graph(True)
     t_build = time.time() - t0
@@ -117,9 +108,11 @@ def main():
     flops_per_image = a.sampler_steps * 2 * FLOPS_UNET_PER_SAMPLE + FLOPS_VAE_DECODE
     gm = ldm.model.graphed  # None with --no-graph
     unet_calls = a.sampler_steps * (a.warmup + a.steps)
-    graph_replay = bool(gm is not None and gm.active and gm.replays >= unet_calls - 2 * gm.captures)
-    if gm is not None and not graph_replay:  # strict capture raises; this catches a silent eager run all the same
-        raise SystemExit(f"hipGraph replay was requested but only {gm.replays} of {unet_calls} UNet calls were replays")
+    # `replays` counts launches of an already captured graph only: with ONE conditioning per run every UNet call but the capturing
+    # one must be a replay.  A run that re-captured per step (a conditioning tensor rebuilt inside the loop) fails here.
+    graph_replay = bool(gm is not None and gm.active and gm.captures == 1 and gm.replays == unet_calls - 1)
+    if gm is not None and not graph_replay:  # strict capture raises; this catches a silent eager / re-capturing run all the same
+        raise SystemExit(f"hipGraph replay was requested but {gm.replays} of {unet_calls} UNet calls were replays ({gm.captures} captures)")
     res = {
         "metric": "images/sec SD1.5 512x512 20-step Euler ancestral (txt2img, CFG 7.5, incl. VAE decode)",
         "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -566,13 +566,7 @@ int launch_conv_ring(crg_ctx* ctx, hipStream_t st, const GemmP& p, int wnt, int 
   const int XP = (p.halo_lin || p.Wo > TP) ? (TP + 2 + 7) / 8 : ((TP / p.Wo) * (p.Wo + 2) + 7) / 8;
   if (XP > 40) return crg_fail(ctx, -22, "conv ring: row buffer of %d pieces unsupported", XP);
   const size_t lds = (size_t)4 * BN * 128 + (size_t)2 * XP * 1024;
-  static bool attr_set[32] = {};
-  const int ai = (wnt == 5 ? 16 : 0) + spread * 4 + (p.pair ? 2 : 0) + (lin ? 1 : 0);
-  if (!attr_set[ai]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return crg_fail(ctx, -5, "conv ring: cannot set dynamic LDS: %s", hipGetErrorString(e));
-    attr_set[ai] = true;
-  }
+  if (int rc = crg_set_dyn_lds(ctx, reinterpret_cast<const void*>(kern), 160 * 1024, "conv ring")) return rc;
   hipLaunchKernelGGL(kern, dim3(p.tile_count * p.splits, 1, 1), dim3(512), lds, st, p);
   CRG_CHECK_LAUNCH(ctx, "conv_ring");
   return 0;

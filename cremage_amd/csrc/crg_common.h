@@ -36,6 +36,7 @@ struct crg_ctx {
   std::vector<void*> retired;  // outgrown scratch buffers (kept alive: captured graphs / queued kernels may reference them)
   void* zero_page = nullptr;  // 4 KiB of zeros: LDS-DMA source for conv padding and tile tails
   unsigned* tile_cnt = nullptr;  // 4096 split-K arrival counters (zero between launches: the last arriver resets its tile's), behind the zero page
+  std::vector<const void*> lds_attr;  // kernels whose dynamic-LDS limit was raised ON THIS CONTEXT'S DEVICE (crg_set_dyn_lds)
   bool profiling = false;
   std::vector<crg_prof_rec> recs;
   std::vector<hipEvent_t> event_pool;
@@ -67,6 +68,17 @@ struct crg_prof_scope {
   } while (0)
 
 static inline size_t crg_dtype_size(int dt) { return dt == CRG_F32 ? 4 : 2; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of the function: remembered per CONTEXT (= per device and
+// lane), not per process - a process that drives several GPUs sets it once on each.  Called outside graph capture by the warm-up.
+static inline int crg_set_dyn_lds(crg_ctx* ctx, const void* kern, size_t bytes, const char* what) {
+  for (const void* k : ctx->lds_attr)
+    if (k == kern) return 0;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return crg_fail(ctx, -5, "%s: cannot set %zu B dynamic LDS: %s", what, bytes, hipGetErrorString(e));
+  ctx->lds_attr.push_back(kern);
+  return 0;
+}
 
 // ---- device helpers -------------------------------------------------------------------------
 // x * sigmoid(x); v_rcp_f32 (1 ulp) instead of an IEEE division sequence

@@ -1028,13 +1028,9 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
       p.ks_r = ngroups % p.splits;
     }
   }
-  static bool attr_set[6] = {false, false, false, false, false, false};
-  const int ai = p.pair + 2 * (halo ? (p.rowhalo == 2 ? 2 : 1) : 0);
-  if (!attr_set[ai]) {
+  {
     const size_t cap = halo ? (size_t)(p.rowhalo == 2 ? 116 : 80) * 1024 : lds;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
-    if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", cap, hipGetErrorString(e));
-    attr_set[ai] = true;
+    if (int rc = crg_set_dyn_lds(ctx, reinterpret_cast<const void*>(kern), cap, "gemm")) return rc;
   }
   dim3 grid(p.tile_count * p.splits, batch, 1);
   constexpr int slot = !GLDS ? (CONV ? CRG_K_CONV_X3 : CRG_K_GEMM_X3)
@@ -1204,12 +1200,9 @@ int launch_planes(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
       units = ngroups;  // ... or in (chunk, kernel row) groups
     }
   }
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[halo]) {
+  {
     const size_t cap = halo ? (size_t)(2 * 2 * BN * 128 + 2 * 2 * 18 * 1024) : lds;  // eligible widths need <= 18 pieces per row buffer
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
-    if (e != hipSuccess) return crg_fail(ctx, -5, "gemm: cannot set %zu B dynamic LDS: %s", cap, hipGetErrorString(e));
-    attr_set[halo] = true;
+    if (int rc = crg_set_dyn_lds(ctx, reinterpret_cast<const void*>(kern), cap, "gemm(planes)")) return rc;
   }
   {
     p.ks_q = units / p.splits;

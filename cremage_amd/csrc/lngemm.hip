@@ -573,13 +573,7 @@ extern "C" int crg_ln_gemm(crg_ctx* ctx, void* stream, const crg_lngemm_args* a)
   else if (wide) { kern = lngemm_kernel<5, 5, false>; bn = 160; }
   else { kern = lngemm_kernel<4, 5, false>; bn = 128; }
   const size_t lds = alias ? (size_t)4 * bn * 128 : (size_t)5 * 128 * 128 + (size_t)4 * bn * 128;
-  static bool attr_set[4] = {};
-  const int ai = alias ? 3 : (geglu ? 0 : (wide ? 1 : 2));
-  if (!attr_set[ai]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return crg_fail(ctx, -5, "ln_gemm: cannot set dynamic LDS: %s", hipGetErrorString(e));
-    attr_set[ai] = true;
-  }
+  if (int rc = crg_set_dyn_lds(ctx, reinterpret_cast<const void*>(kern), 160 * 1024, "ln_gemm")) return rc;
   const double flops = 2.0 * a->M * (double)a->N * a->K;
   const double bytes = (double)a->M * a->K * 2 + (double)a->N * a->K * 2 + (double)a->M * n_out * 2;
   crg_prof_scope ps(ctx, st, CRG_K_LNGEMM, flops, bytes);

@@ -18,10 +18,13 @@ Correctness rules enforced here:
     which overwrites the modules' single-slot caches, cannot free memory an older graph still reads
     (ctx A -> ctx B -> ctx A replays graph A against its own, still-live K/V);
   * a graph is keyed on a WEIGHT STAMP as well: the (data_ptr, _version) of every parameter of the module (about 0.1 ms of
-    host time per call, overlapped with the previous replay) and an epoch that is bumped whenever a Parameter is registered
-    on any module (LoRA `setattr`, image_generator.py:408-453) or a packed weight image is rebuilt.  load_state_dict
-    (in-place copy -> version), `.to()` / `.half()` (new storage -> data_ptr) and LoRA swaps therefore re-capture instead of
-    replaying against stale or freed weight images; `invalidate()` remains for writes through `.data`, which no counter sees;
+    host time per call, overlapped with the previous replay; the parameter list is re-read when `TensorKeyedCache.epoch`
+    moves, i.e. when a Parameter is registered on any module - LoRA `setattr`, image_generator.py:408-453 - or a derived
+    image is rebuilt) plus `TensorKeyedCache.generation`, which moves whenever a derived-weight cache DROPS its values
+    (`ops.clear_weight_cache()`, the overflow clear): the packed / stacked / merged images a capture baked in are freed there
+    although no parameter changed.  load_state_dict (in-place copy -> version), `.to()` / `.half()` (new storage ->
+    data_ptr), LoRA swaps and cache clears therefore re-capture instead of replaying against stale or freed weight images;
+    `invalidate()` remains for writes through `.data`, which no counter sees;
   * a failed capture RAISES (`strict=True`, the default): the caller asked for replay, and a silent switch to eager
     launches would make a timing unattributable.  `strict=False` restores the warn-and-go-eager behaviour.
 """
@@ -54,14 +57,14 @@ class GraphedModule:
         self.strict = strict
         self._graphs: Dict[tuple, tuple] = {}
         self.broken = False
-        self.replays = 0     # graph launches so far (bench.py reports whether its timed steps were replays)
+        self.replays = 0     # launches of an ALREADY captured graph (the call that captures is not counted: bench.py checks that its timed steps were replays)
         self.captures = 0
         self._params = None  # (epoch, [parameters]) - the list is rebuilt when the epoch moves
 
     def _weight_stamp(self):
         if self._params is None or self._params[0] != TensorKeyedCache.epoch:
             self._params = (TensorKeyedCache.epoch, list(self.module.parameters()))
-        return hash(tuple((q.data_ptr(), q._version) for q in self._params[1]))
+        return hash((TensorKeyedCache.generation,) + tuple((q.data_ptr(), q._version) for q in self._params[1]))
 
     @property
     def active(self) -> bool:
@@ -98,6 +101,7 @@ class GraphedModule:
         if g is not None and g[5] != self._weight_stamp():  # weights changed since the capture: its packed images are stale
             del self._graphs[key]
             g = None
+        fresh = g is None
         if g is None:
             try:
                 g = self._capture(key, x, dyn, consts, other)
@@ -114,7 +118,8 @@ class GraphedModule:
         for k, v in dyn.items():
             sdyn[k].copy_(v)
         graph.replay()
-        self.replays += 1
+        if not fresh:
+            self.replays += 1
         return sout.clone()
 
     def _capture(self, key, x, dyn, consts, other):

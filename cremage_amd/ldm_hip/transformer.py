@@ -114,7 +114,7 @@ class GEGLU_with_lora(nn.Module):
         row-resident kernel takes the shape (ops.ln_linear_ok), as a separate pass otherwise."""
         w = _eff(self, self.proj.weight, "proj")
         if ln is not None:
-            if ops.ln_linear_ok(x, w):
+            if ops.ln_linear_ok(x, w, act="geglu"):
                 return ops.ln_linear(x, ln.weight, ln.bias, ln.eps, w, self.proj.bias, act="geglu")
             x = ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
         return ops.linear(x, w, self.proj.bias, act="geglu")
@@ -231,7 +231,7 @@ class CrossAttention(nn.Module):
             if self.ipa_num_tokens > 0:
                 raise NotImplementedError("ipa_num_tokens > 0 needs a context (attention.py:623-627)")
             wqkv = self._stack(wq, wk, wv) if fused else None
-            if fused and _SELF_QKV and ln is not None and ops.ln_linear_ok(x, wqkv) and x.dim() == 3 and (2 * c) % 160 == 0:
+            if fused and _SELF_QKV and ln is not None and ops.ln_linear_ok(x, wqkv, transposed_from=2 * c):
                 # 64x64 level: LayerNorm + Q | K | V in ONE launch whose V third is written transposed, so that the 4096-token
                 # self-attention runs on the transposed-V flash kernel (the row-major-V variant is 10-20 % slower there)
                 qk, vt = ops.ln_linear(x, ln.weight, ln.bias, ln.eps, wqkv, transposed_from=2 * c)

@@ -104,7 +104,7 @@ class TensorKeyedCache:
     def put(self, tensors, extra, value):
         import weakref
         if len(self._d) >= self._max:
-            self._d.clear()
+            self.clear()
         key = (tuple(id(t) for t in tensors), extra)
         d = self._d
 
@@ -115,13 +115,17 @@ class TensorKeyedCache:
         TensorKeyedCache.epoch += 1
         return value
 
-    # bumped whenever ANY derived weight image is (re)built: captured hipGraphs bake the addresses of the images they were
-    # captured with, so cremage_amd.graphs drops a graph whose capture-time epoch is stale (load_state_dict, LoRA setattr and
-    # .to() all land here through their cache miss)
+    # bumped whenever ANY derived weight image is (re)built or a Parameter is registered: cremage_amd.graphs re-lists the module's
+    # parameters when it moves (the weight stamp itself is the parameters' (data_ptr, _version))
     epoch = 0
+    # bumped whenever ANY cache DROPS its values (clear(), or the overflow clear in put()): a captured hipGraph bakes in the
+    # addresses of the packed / stacked / merged images it was warmed up with, and those are freed here while the parameters -
+    # and with them the weight stamp - stay what they were.  The generation is part of the stamp, so such a graph is re-captured.
+    generation = 0
 
     def clear(self):
         self._d.clear()
+        TensorKeyedCache.generation += 1
 
 
 _ROWRES = __import__("os").environ.get("CRG_ROWRES", "0") != "0"  # dev knob: 1 = route plain K = 320 GEMMs with >= 16384 rows to the row-resident kernel
@@ -338,9 +342,28 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return y
 
 
-def ln_linear_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
-    """Shapes crg_ln_gemm takes (the row-resident LayerNorm + GEMM kernel): bf16 tokens of width 320."""
-    return x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 320 and weight[0].numel() == 320 and weight.shape[0] % 16 == 0
+def ln_linear_ok(x: torch.Tensor, weight: torch.Tensor, act: Optional[str] = None, transposed_from: Optional[int] = None) -> bool:
+    """Every precondition crg_ln_gemm enforces (the row-resident LayerNorm + GEMM kernel), so that callers can route on this
+    predicate ALONE and fall back to layer_norm + linear otherwise: bf16 tokens of width 320; N a multiple of 8 (GEGLU: of 32,
+    packed value / gate groups); a transposed column range starts on a tile boundary (tile = 160 columns when N % 160 == 0, else
+    128) of a [B, T, K] input without activation; x, w and y (and the V^T output) each below 2 GiB."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 320 and weight[0].numel() == 320):
+        return False
+    N = weight.shape[0]
+    M = x.numel() // 320
+    geglu = act == "geglu"
+    if act not in (None, "geglu") or N % (32 if geglu else 8):
+        return False
+    n_out = N // 2 if geglu else N
+    if transposed_from is not None:
+        bn = 160 if N % 160 == 0 else 128
+        if geglu or x.dim() != 3 or not (0 < transposed_from < N) or transposed_from % bn:
+            return False
+        ld = (x.shape[1] + 7) // 8 * 8
+        if x.shape[0] * (N - transposed_from) * ld * 2 >= (1 << 31):
+            return False
+        n_out = transposed_from
+    return max(M * 320, N * 320, M * n_out) * 2 < (1 << 31)
 
 
 def ln_linear(x: torch.Tensor, ln_weight, ln_bias, eps: float, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
@@ -351,8 +374,8 @@ def ln_linear(x: torch.Tensor, ln_weight, ln_bias, eps: float, weight: torch.Ten
     ld = roundup(T, 8), i.e. transposed per sample (the V^T operand of `attention`); the first tensor then has n0 columns.
     ln_weight = ln_bias = None: no LayerNorm (row-resident plain GEMM); `residual` ([.., N], bf16) is added after the bias."""
     _need_cuda(x, ln_weight, ln_bias, weight, bias)
-    if not ln_linear_ok(x, weight):
-        raise L.CrgError("ln_linear: bf16 tokens of width 320 expected (use layer_norm + linear)")
+    if not ln_linear_ok(x, weight, act, transposed_from):
+        raise L.CrgError("ln_linear: shape outside the row-resident kernel's domain (test ln_linear_ok, else layer_norm + linear)")
     x = x.contiguous()
     K = x.shape[-1]
     M = x.numel() // K
@@ -507,6 +530,9 @@ def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias=None, residual: Optional
 
 
 # ---------------------------------------------------------------------------------- attention
+SCORE_BUDGET_BYTES = 256 << 20  # fp32 score buffer of the unfused attention path (queries are processed in chunks that fit it)
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, n_keys: int, scale: float) -> torch.Tensor:
     """softmax(Q K^T * scale) V with heads split along the channel dim.
     q: [B, Nq, C], k: [B, Nk, C], vt: [B, C, ld] (V transposed, ld = roundup(Nk, 8)) -> [B, Nq, C]."""
@@ -546,7 +572,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, n_
         return th, tl
     kh, kl = planes(k)            # [B, Nk, C]
     vh, vl = planes(vt)           # [B, C, ld]
-    qc = max(8, min(Nq, (256 << 20) // (4 * heads * kp) // 8 * 8))  # queries per chunk
+    qc = max(8, min(Nq, SCORE_BUDGET_BYTES // (4 * heads * kp) // 8 * 8))  # queries per chunk
     s = torch.empty((heads, min(qc, Nq), kp), dtype=torch.float32, device=q.device)
     if kp != n_keys:
         s[:, :, n_keys:].zero_()

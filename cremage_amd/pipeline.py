@@ -47,6 +47,22 @@ def build_synthetic_ldm(unet_cfg=None, vae_dd=None, device="cuda", unet_dtype=to
     return ldm.to(device).eval()
 
 
+def build_ldm_sharded(rank: int, device, unet_cfg=None, vae_dd=None, unet_dtype=torch.bfloat16, vae_dtype=torch.float32, seed: int = 1234):
+    """The model of one rank of a batch-sharded run (bench.py --gpus N; tests/test_dist_cpu.py runs this very function under gloo):
+    rank 0 materialises the synthetic weights, every other rank builds the same module tree UNINITIALISED in the same dtypes and
+    receives parameters + buffers through ONE flat broadcast per (dtype, device) bucket (dist.broadcast_module_, whose header check
+    makes every rank raise if the trees differ).  Returns (ldm, bytes broadcast)."""
+    from . import dist as D
+    if rank == 0:
+        ldm = build_synthetic_ldm(unet_cfg, vae_dd, device=device, unet_dtype=unet_dtype, vae_dtype=vae_dtype, seed=seed)
+    else:
+        ldm = LatentDiffusion(UNetModel(**(unet_cfg or SD15_UNET)), AutoencoderKL(vae_dd or SD15_VAE_DD, None, 4))
+        ldm.model.to(unet_dtype)
+        ldm.first_stage_model.to(vae_dtype)
+        ldm = ldm.to(device).eval()
+    return ldm, D.broadcast_module_(ldm, src=0)
+
+
 def build_synthetic_control_ldm(unet_cfg=None, vae_dd=None, device="cuda", unet_dtype=torch.bfloat16, vae_dtype=torch.float32, seed: int = 1234):
     """ControlLDM (cldm.py:345-393, cldm_v15.yaml) with name-keyed synthetic weights: ControlledUnetModel + ControlNet + VAE."""
     from .cldm_hip import ControlLDM, ControlledUnetModel, ControlNet

@@ -96,6 +96,48 @@ def test_gloo_world2_broadcast_of_mismatched_models_fails_on_every_rank():
     assert all("built differently" in res[r] for r in range(world)), res
 
 
+def _worker_bench_model(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from cremage_amd import dist as D
+    from cremage_amd import pipeline as P
+    D.init_from_env(backend="gloo")
+    torch.manual_seed(1000 + rank)  # the uninitialised tree of rank != 0 starts from different values
+    unet_cfg = dict(P.SD15_UNET, model_channels=32, num_heads=4, context_dim=64)
+    vae_dd = dict(P.SD15_VAE_DD, ch=32, ch_mult=[1, 2], num_res_blocks=1, resolution=32)
+    ldm, sent = P.build_ldm_sharded(rank, "cpu", unet_cfg=unet_cfg, vae_dd=vae_dd)
+    names = [n for n, _ in ldm.named_parameters()] + [n for n, _ in ldm.named_buffers()]
+    dtypes = sorted({str(p.dtype) for p in ldm.parameters()})
+    flat = torch.cat([t.detach().float().reshape(-1) for t in list(ldm.parameters()) + list(ldm.buffers())])
+    q.put((rank, sent, names, dtypes, flat.numpy()))  # by value: a shared-memory tensor would need this process to outlive the read
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_world2_bench_model_construction_branches():
+    """bench.py's own model construction (pipeline.build_ldm_sharded) on both of its branches: rank 0 fills the synthetic weights,
+    rank 1 builds the uninitialised tree (`.to(bf16)` on the UNet only), and ONE broadcast_module_ leaves rank 1 with rank 0's
+    parameters and buffers - i.e. the bucket order the header check guards is the order the real code produces."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bench_model, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=300)
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] > 0
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3] == ["torch.bfloat16", "torch.float32"]
+    import numpy as np
+    assert np.isfinite(res[0][4]).all() and np.abs(res[0][4]).sum() > 0
+    assert np.array_equal(res[0][4], res[1][4])
+
+
 def test_shard_range_partitions_everything():
     from cremage_amd import dist as D
     for n in [0, 1, 7, 16, 33]:

@@ -791,9 +791,39 @@ def test_hip_graph_owns_its_kv_cache_across_context_switches():
                 del junk
                 gc.collect()
                 assert torch.equal(y, ref[i]), (rnd_, i)
-        assert gm.captures == 2 and gm.replays == 12
+        assert gm.captures == 2 and gm.replays == 10  # 12 calls, the two capturing ones are not replays
         # a rebuilt weight image (here: in-place weight edit -> _version bump -> repack on the next eager use) invalidates
         w = m.input_blocks[1][0].in_layers[2].weight
         w.mul_(1.0)  # same values, new version
         y = gm(x, timesteps=t, context=ctxs[0])
         assert torch.equal(y, ref[0]) and gm.captures == 3
+
+
+def test_hip_graph_recaptures_after_weight_cache_clear():
+    """ops.clear_weight_cache() frees the packed / stacked / fp32 images a captured graph baked in while no parameter changes:
+    the cache generation is part of the graph's weight stamp, so the next call re-captures (and is right) instead of replaying
+    against freed memory."""
+    import gc
+    from cremage_amd import ops
+    from cremage_amd.graphs import GraphedModule
+    from cremage_amd.ldm_hip.unet import UNetModel
+    meta, g = load_golden("unet_small_sd")
+    cfg = meta["cfg"]
+    m = prep(UNetModel(**cfg), meta, BF)
+    gm = GraphedModule(m, scratch_bytes=64 << 20)
+    ctx = synth_input("graph3.ctx", (4, 77, cfg["context_dim"]), 9).to(DEV)
+    x = synth_input("graph3.x", (4, 4, 16, 16), 5).to(DEV)
+    t = torch.full((4,), 650.25, device=DEV)
+    with torch.no_grad():
+        ref = m(x, timesteps=t, context=ctx).clone()
+        assert torch.equal(gm(x, timesteps=t, context=ctx), ref)
+        assert torch.equal(gm(x, timesteps=t, context=ctx), ref)
+        assert gm.captures == 1 and gm.replays == 1
+        ops.clear_weight_cache()
+        gc.collect()
+        junk = [torch.full((1 << 20,), 3.0, device=DEV, dtype=torch.bfloat16) for _ in range(16)]  # reuse whatever was freed
+        y = gm(x, timesteps=t, context=ctx)
+        del junk
+        assert gm.captures == 2, "a cache clear must invalidate the captured graph"
+        assert torch.equal(y, ref)
+        assert torch.equal(gm(x, timesteps=t, context=ctx), ref) and gm.replays == 2

@@ -626,6 +626,23 @@ def test_unfused_attention(dtype, heads, d):
     assert rel < (1e-2 if dtype == BF else 5e-5), rel
 
 
+@pytest.mark.parametrize("dtype,heads,d", [(BF, 1, 512), (torch.float32, 1, 512), (torch.float32, 4, 32)])
+def test_unfused_attention_query_chunks_with_tail(dtype, heads, d, monkeypatch):
+    """The chunked unfused path with SEVERAL query chunks plus a shorter last one and a padded key count (kp != n_keys): the
+    branch the VAE AttnBlock takes at 768x768 (9216 tokens: chunks of 7280 + a tail of 1936).  The score budget is shrunk so that
+    a small case walks the same code: Nq = 150 in chunks of 64 -> 64, 64, 22."""
+    from cremage_amd import ops
+    C, Nq, Nk = heads * d, 150, 77
+    kp = (Nk + 7) // 8 * 8
+    monkeypatch.setattr(ops, "SCORE_BUDGET_BYTES", 4 * heads * kp * 64)
+    qq, kk, vv = rnd(2, Nq, C, seed=86), rnd(2, Nk, C, seed=87), rnd(2, Nk, C, seed=88)
+    vt = F.pad(vv.transpose(1, 2), (0, (-Nk) % 8)).contiguous()
+    ref = attn_ref(q(qq, dtype), q(kk, dtype), q(vv, dtype), heads, d ** -0.5)
+    got = ops.attention(qq.to(_dev()).to(dtype), kk.to(_dev()).to(dtype), vt.to(_dev()).to(dtype), heads, Nk, d ** -0.5).float().cpu()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < (1e-2 if dtype == BF else 5e-5), rel
+
+
 # ------------------------------------------------------------------------------------------ small ops
 def test_timestep_embedding_kernel(golden):
     from cremage_amd import ops
