@@ -370,6 +370,234 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
   }
 }
 
+// ---- few keys (Nk <= 128): the cross-attentions against the 77-token prompt context, FaceID's four tokens, 8x8 self-attention ----
+// Same mathematics, MFMA layout and LDS images as attn_kernel, different loop nest.  With at most two 64-key tiles the whole K / V of a
+// (batch, head) fits the two LDS stages, and what attn_kernel spends its time on at these sizes is per-BLOCK cost - zeroing and
+// staging the tiles, three block barriers, the launch of 2048 blocks for 32768 x 8 query rows - not arithmetic (26-29 us for a
+// 4096-query cross-attention whose MFMAs take 3).  Here a block stages the K / V tiles ONCE and then walks several 128-query
+// groups of its (batch, head) with no barrier at all: Q fragments from HBM, S^T = K Q^T, online softmax over the (one or two) tiles,
+// O^T += V^T P^T, normalise, store.  The grid is (groups-per-block divisor, B * H), sized to at most four blocks per CU.
+template <int KS, int NV, bool ONES, bool VRM>
+__global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_ctx_kernel(AttnP p) {
+  constexpr int KROW = KS * 32 + 16;
+  constexpr int KCH = 2 * KS;
+  constexpr int KLOADS = (64 * KCH + 255) / 256;
+  constexpr int KBYTES = 64 * KROW;
+  constexpr int VBYTES = VRM ? NV * 4096 : NV * 32 * VROW;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (KBYTES + VBYTES)];  // stage = key tile (at most two)
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int by = blockIdx.y;
+  const int b = by / p.H, h = by % p.H;
+  const bf16* Q = p.q + (long)b * p.Nq * p.ldq + (long)h * p.Dh;
+  const bf16* K = p.k + (long)b * p.Nk * p.ldk + (long)h * p.Dh;
+  const bf16* VT = VRM ? p.vt + (long)b * p.Nk * p.ldvt + (long)h * p.Dh : p.vt + ((long)b * p.H + h) * p.Dh * p.ldvt;
+  bf16* O = p.o + (long)b * p.Nq * p.ldo + (long)h * p.Dh;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bf16 one = (bf16)1.0f;
+  const bf16x8 ones8 = {one, one, one, one, one, one, one, one};
+  constexpr bool ones_row = ONES;  // softmax denominator on the matrix core (see attn_kernel)
+  const int ntiles = (p.Nk + 63) >> 6;  // 1 or 2 (launcher)
+
+  // ---- stage every key tile once (bounds-checked form: tails are the normal case here) ----
+  if constexpr (VRM) {
+    uint4* z = reinterpret_cast<uint4*>(smem);
+    for (int i = t; i < 2 * (KBYTES + VBYTES) / 16; i += 256) z[i] = uint4{0, 0, 0, 0};
+    __syncthreads();
+    if (ones_row && t < 128) {
+      const int st = t >> 6, key = t & 63;
+      const int blk = p.Dh >> 5, col = p.Dh & 31;
+      *reinterpret_cast<bf16*>(smem + st * (KBYTES + VBYTES) + KBYTES + blk * 4096 + key * 64 + col * 2) = one;
+    }
+    __syncthreads();
+  }
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int kbase = tile * 64;
+    char* Ks = smem + tile * (KBYTES + VBYTES);
+    char* Vs = Ks + KBYTES;
+#pragma unroll
+    for (int i = 0; i < KLOADS; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx / KCH, c = idx - row * KCH;
+      if (idx < 64 * KCH) {
+        const bool ok = c * 8 < p.Dh && kbase + row < p.Nk;
+        *reinterpret_cast<bf16x8*>(Ks + row * KROW + c * 16) = ok ? *reinterpret_cast<const bf16x8*>(K + (long)(kbase + row) * p.ldk + c * 8) : zero8;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = t + 256 * i;
+      if constexpr (VRM) {  // chunk slot (key, c): channels 8c .. 8c + 7 of one key; constant slots (zeros, the ones column) stay
+        const int key = idx / (4 * NV), c = idx - key * (4 * NV);
+        if (c * 8 < p.Dh) {
+          const bf16x8 v = kbase + key < p.Nk ? *reinterpret_cast<const bf16x8*>(VT + (long)(kbase + key) * p.ldvt + c * 8) : zero8;
+          *reinterpret_cast<bf16x8*>(Vs + (c >> 2) * 4096 + key * 64 + (c & 3) * 16) = v;
+        }
+      } else {
+        const int row = idx >> 3, c = idx & 7;
+        const int key0 = kbase + c * 8;
+        bf16x8 v = zero8;
+        if (row < p.Dh && key0 < p.Nk) {
+          v = *reinterpret_cast<const bf16x8*>(VT + (long)row * p.ldvt + key0);
+          if (key0 + 8 > p.Nk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (key0 + e >= p.Nk) v[e] = (bf16)0.f;
+          }
+        } else if (ones_row && row == p.Dh) {
+          v = ones8;
+        }
+        const uint2* src = reinterpret_cast<const uint2*>(&v);
+        uint2* dst = reinterpret_cast<uint2*>(Vs + row * VROW + c * 16);  // rows are only 8-byte aligned
+        dst[0] = src[0];
+        dst[1] = src[1];
+      }
+    }
+  }
+  __syncthreads();
+
+  const int nqg = (p.Nq + 127) >> 7;
+  // Q fragments of the NEXT group are requested before the current group is multiplied (a wave walks its groups back to back:
+  // without the prefetch every group starts with an exposed HBM round trip)
+  auto load_q = [&](bf16x8 (&dst)[KS], int qg) {
+    const int qq = qg * 128 + wave * 32 + r;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int d0 = 16 * s + 8 * hh;
+      dst[s] = (qg < nqg && qq < p.Nq && d0 < p.Dh) ? *reinterpret_cast<const bf16x8*>(Q + (long)qq * p.ldq + d0) : zero8;
+    }
+  };
+  bf16x8 qf[KS], qn[KS];
+  load_q(qn, blockIdx.x);
+  for (int qg = blockIdx.x; qg < nqg; qg += gridDim.x) {
+    const int query = qg * 128 + wave * 32 + r;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = qn[s];
+    load_q(qn, qg + gridDim.x);
+    f32x16 oacc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int tile = 0; tile < ntiles; ++tile) {
+      const char* Ks = smem + tile * (KBYTES + VBYTES);
+      const char* Vs = Ks + KBYTES;
+      f32x16 st[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[kb][e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kb * 32 + r) * KROW + (2 * s + hh) * 16);
+          st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kb], 0, 0, 0);
+        }
+      }
+      if ((tile + 1 == ntiles) && (p.Nk & 63)) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int key = tile * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            if (key >= p.Nk) st[kb][e] = -INFINITY;
+          }
+      }
+      float mx = fmaxf(fmaxf(st[0][0], st[1][0]), st[0][1]);
+#pragma unroll
+      for (int e = 1; e < 15; ++e) mx = fmaxf(fmaxf(mx, st[1][e]), st[0][e + 1]);
+      mx = fmaxf(mx, st[1][15]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;
+      const float m_new = fmaxf(m_run, mx);
+      if (__any(m_new != m_run)) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+        m_run = m_new;
+      }
+      float rs = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        st[kb] = st[kb] * p.scale_log2 - m_run;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pe = __builtin_amdgcn_exp2f(st[kb][e]);
+          st[kb][e] = pe;
+          if (!ones_row) rs += pe;
+        }
+      }
+      if (!ones_row) l_run += rs;
+      bf16x8 pf[2][2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[kb][s2][j] = (bf16)st[kb][8 * s2 + j];
+#pragma unroll
+      for (int dv = 0; dv < NV; ++dv) {
+        const char* vrow = Vs + (dv * 32 + r) * VROW;
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4* trptr_t;
+        const char* vtr = Vs + dv * 4096 + (4 * (lane >> 5) + ((lane >> 2) & 3)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 vf;
+            if constexpr (VRM) {
+              const char* a0 = vtr + (kb * 32 + 16 * s2) * 64;
+              const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)a0);
+              const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)(a0 + 8 * 64));
+              const short v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+              __builtin_memcpy(&vf, v8, 16);
+            } else {
+              const int keyoff = kb * 32 + 16 * s2 + 4 * hh;
+              const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + keyoff * 2);
+              const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + (keyoff + 8) * 2);
+              vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            oacc[dv] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], oacc[dv], 0, 0, 0);
+          }
+      }
+    }
+    float l_tot;
+    if (ones_row) {
+      const int dvl = p.Dh >> 5, regl = ((p.Dh & 31) >> 3) * 4;
+      float v = 0.f;
+#pragma unroll
+      for (int dv = 0; dv < NV; ++dv)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (dv == dvl && 4 * g == regl) v = oacc[dv][4 * g];
+      const float other = __shfl_xor(v, 32);
+      l_tot = hh == 0 ? v : other;
+    } else {
+      l_tot = l_run + __shfl_xor(l_run, 32);
+    }
+    const float inv = 1.0f / l_tot;
+    if (query < p.Nq) {
+#pragma unroll
+      for (int dv = 0; dv < NV; ++dv)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = dv * 32 + 8 * g + 4 * hh;
+          if (d < p.Dh) {
+            bf16x4 o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o4[e] = (bf16)(oacc[dv][4 * g + e] * inv);
+            *reinterpret_cast<bf16x4*>(O + (long)query * p.ldo + d) = o4;
+          }
+        }
+    }
+  }
+}
+
 // ---- LDS-DMA form (Nk % 64 == 0, V^T from HBM) ---------------------------------------------------------------------------
 // Same mathematics and MFMA layout as attn_kernel, but the K / V^T tiles go HBM -> LDS by buffer_load ... lds: no staging
 // registers, no ds_write commit, no vmcnt(0) in front of a store (115 instead of 152 VGPRs at d_head 40).  The SIMD's vector issue
@@ -1044,6 +1272,26 @@ int launch_attn_sp(crg_ctx* ctx, hipStream_t st, const AttnP& p) {
 }
 
 template <int KS, int NV>
+int launch_attn_ctx(crg_ctx* ctx, hipStream_t st, const AttnP& p, bool vrm) {
+  // blocks per (batch, head): the largest divisor of the 128-query group count that keeps the grid within four blocks per CU,
+  // so that every block walks the same number of groups behind ONE staging of the key tiles
+  const int nqg = (p.Nq + 127) / 128, bh = p.B * p.H;
+  int gx = 1;
+  for (int d = 1; d <= nqg; ++d)
+    if (nqg % d == 0 && (long)d * bh <= 1024) gx = d;
+  dim3 grid(gx, bh);
+  if (vrm) {
+    if (p.Dh < NV * 32) hipLaunchKernelGGL((attn_ctx_kernel<KS, NV, true, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_ctx_kernel<KS, NV, false, true>), grid, dim3(256), 0, st, p);
+  } else {
+    if (p.Dh < NV * 32) hipLaunchKernelGGL((attn_ctx_kernel<KS, NV, true, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_ctx_kernel<KS, NV, false, false>), grid, dim3(256), 0, st, p);
+  }
+  CRG_CHECK_LAUNCH(ctx, "attention (few keys)");
+  return 0;
+}
+
+template <int KS, int NV>
 int launch_attn(crg_ctx* ctx, hipStream_t st, const AttnP& p, bool vrm) {
   dim3 grid((p.Nq + 127) / 128, p.B * p.H);
   if (vrm) {
@@ -1076,6 +1324,28 @@ static int attention_entry(crg_ctx* ctx, void* stream, const void* q, int64_t ld
   const double bytes = 2.0 * B * H * Dh * (2.0 * Nq + 2.0 * Nk);
   crg_prof_scope ps(ctx, st, CRG_K_ATTN, flops, bytes);
   const int ks = (Dh + 15) / 16;
+  // few keys (cross-attention against the prompt context, FaceID tokens, 8x8 self-attention): K / V staged once per block, no barrier
+  // in the loop.  CRG_ATTN_CTX (developer knob): 0 = the general kernels for these shapes too
+  static const int use_ctx = getenv("CRG_ATTN_CTX") ? atoi(getenv("CRG_ATTN_CTX")) : 1;
+  // ... used where a block then walks at least two query groups behind one staging of the keys (measured, kernel trace: 8 x 4096
+  // queries x 77 keys, d 40: 22.3 -> 19.6 us; with ONE group per block - 1024 queries, d 80 - the general kernel's interior-tile
+  // staging is the faster one, 12.6 vs 13.5 us).  These launches are bound by their 80-byte-per-head Q / O row slices (32 cache
+  // lines per wave-instruction), not by block count: see DESIGN 4.
+  const int nqg_ = (Nq + 127) / 128;
+  if (use_ctx && Nk <= 128 && (long)nqg_ * B * H >= 2048) {
+    switch (ks) {
+      case 1: return launch_attn_ctx<1, 1>(ctx, st, p, vrm);
+      case 2: return launch_attn_ctx<2, 1>(ctx, st, p, vrm);
+      case 3: return launch_attn_ctx<3, 2>(ctx, st, p, vrm);
+      case 4: return launch_attn_ctx<4, 2>(ctx, st, p, vrm);
+      case 5: return launch_attn_ctx<5, 3>(ctx, st, p, vrm);
+      case 6: return launch_attn_ctx<6, 3>(ctx, st, p, vrm);
+      case 7: return launch_attn_ctx<7, 4>(ctx, st, p, vrm);
+      case 8: return launch_attn_ctx<8, 4>(ctx, st, p, vrm);
+      case 9: return launch_attn_ctx<9, 5>(ctx, st, p, vrm);
+      case 10: return launch_attn_ctx<10, 5>(ctx, st, p, vrm);
+    }
+  }
   // LDS-DMA forms: transposed V, whole 64-key tiles, extents addressable through a 32-bit buffer descriptor.
   // CRG_ATTN_DMA (developer knob): 0 = register-staged kernel only, 1 (default) = software-pipelined where instantiated, else the
   // plain LDS-DMA kernel, 8 / 4 = plain LDS-DMA kernel on 8 / 4 waves
