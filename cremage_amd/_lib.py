@@ -38,6 +38,7 @@ class GemmArgs(C.Structure):
         ("a_dtype", c_int), ("y_dtype", c_int), ("prec", c_int),
         ("a_is_weight", c_int),
         ("a_lo", c_void_p),
+        ("gn_stats", c_void_p),
     ]
 
 
@@ -68,6 +69,7 @@ class ConvArgs(C.Structure):
         ("upsample2x", c_int),
         ("x_dtype", c_int), ("y_dtype", c_int), ("prec", c_int),
         ("x_lo", c_void_p),
+        ("gn_stats", c_void_p),
     ]
 
 
@@ -90,6 +92,8 @@ SIGNATURES = {
                               c_int, c_float, c_int, c_int]),
     "crg_groupnorm_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                     c_int, c_float, c_int]),
+    "crg_groupnorm_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                  c_int, c_int, c_float, c_int, c_int]),
     "crg_split_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "crg_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int]),
     "crg_gemm": (c_int, [c_void_p, c_void_p, C.POINTER(GemmArgs)]),
@@ -135,8 +139,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.crg_version() != 100:
-        raise CrgError(f"libcrg_hip.so version {lib.crg_version()} does not match the binding (100)")
+    if lib.crg_version() != 101:
+        raise CrgError(f"libcrg_hip.so version {lib.crg_version()} does not match the binding (101)")
     _lib = lib
     return lib
 

@@ -931,6 +931,95 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p) {
   }
 }
 
+// Split-K second pass that ALSO emits the GroupNorm statistics side channel (GemmP::gstat): same arithmetic per element as
+// splitk_reduce_kernel, but a block owns a 32-row x 128-column patch - thread = (row lane 0..7: rows 4 rl .. 4 rl + 3, column group
+// of 4 channels) - so that the per-channel sums of the rounded outputs over the 32 rows are a fixed-order fold of 8 row lanes
+// through LDS.  grid (row blocks, column patches).
+template <typename YT>
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmP p) {
+  __shared__ __attribute__((aligned(16))) float red[8 * 32 * 8];
+  const int t = threadIdx.x, cg = t & 31, rl = t >> 5;
+  const long srows = p.M - p.slab_row0;
+  const float* S = p.slab - (long)p.slab_row0 * p.N;
+  YT* Y = reinterpret_cast<YT*>(p.y);
+  const YT* R = p.res ? reinterpret_cast<const YT*>(p.res) : nullptr;
+  const int n = blockIdx.y * 128 + cg * 4;
+  const int mb = p.slab_row0 + blockIdx.x * 32;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n < p.N) {
+    f32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mb + rl * 4 + i;
+      const int mc = m < p.M ? m : p.M - 1;  // clamped: the loads stay unconditional, the result of a row past M is dropped
+      v[i] = *reinterpret_cast<const f32x4*>(S + (long)mc * p.N + n);
+      for (int s = 1; s < p.splits; ++s) v[i] += *reinterpret_cast<const f32x4*>(S + ((long)s * srows + mc) * p.N + n);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mb + rl * 4 + i;
+      if (m >= p.M) continue;
+      f32x4 w = v[i];
+      if (p.bias_mode == CRG_BIAS_COL) w += *reinterpret_cast<const f32x4*>(p.bias + n);
+      else if (p.bias_mode == CRG_BIAS_ROW) w += p.bias[m];
+      if (p.epi == CRG_EPI_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = crg_silu_f(w[e]);
+      }
+      if (p.cvec) w += *reinterpret_cast<const f32x4*>(p.cvec + (long)(m / p.cvec_rows) * p.cvec_ld + n);
+      if (R) {
+        const YT* rp = R + (long)m * p.ldr + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] += (float)rp[e];
+      }
+      YT o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (YT)w[e];
+        const float f = (float)o[e];
+        s1[e] += f;
+        s2[e] += f * f;
+      }
+      YT* yp = Y + (long)m * p.ldy + n;
+      if constexpr (sizeof(YT) == 2) *reinterpret_cast<uint2*>(yp) = *reinterpret_cast<const uint2*>(o);
+      else *reinterpret_cast<f32x4*>(yp) = *reinterpret_cast<const f32x4*>(o);
+    }
+  }
+  float* q = red + (rl * 32 + cg) * 8;
+  *reinterpret_cast<f32x4*>(q) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+  *reinterpret_cast<f32x4*>(q + 4) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+  __syncthreads();
+  if (rl == 0 && n < p.N) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(q), b = *reinterpret_cast<const f32x4*>(q + 4);
+#pragma unroll
+    for (int r2 = 1; r2 < 8; ++r2) {
+      a += *reinterpret_cast<const f32x4*>(q + r2 * 32 * 8);
+      b += *reinterpret_cast<const f32x4*>(q + r2 * 32 * 8 + 4);
+    }
+    const long rb = mb >> 5;
+    *reinterpret_cast<f32x4*>(p.gstat + rb * p.N + n) = a;
+    *reinterpret_cast<f32x4*>(p.gstat + p.gstat_plane + rb * p.N + n) = b;
+  }
+}
+
+// the reduce launch behind a split-K launch (whole problem, or - tail split - the rows >= slab_row0)
+template <typename YT>
+int launch_reduce(crg_ctx* ctx, hipStream_t st, const GemmP& p, int batch) {
+  const long rows = p.M - p.slab_row0;
+  crg_prof_scope ps(ctx, st, CRG_K_SPLITK, (double)batch * p.splits * rows * p.N, (double)batch * rows * p.N * (4.0 * p.splits + sizeof(YT)));
+  if (p.gstat) {
+    if (batch != 1 || (p.N & 3) || (p.ldy & 3) || (p.slab_row0 & 31) || (p.res && (p.ldr & 3)))
+      return crg_fail(ctx, -22, "gemm: GroupNorm statistics need an unbatched problem with 4-aligned N / ldy / ldr");
+    hipLaunchKernelGGL(splitk_reduce_stats_kernel<YT>, dim3((unsigned)((rows + 31) / 32), (unsigned)((p.N + 127) / 128)), dim3(256), 0, st, p);
+  } else {
+    const long total4 = rows * (p.N >> 2);
+    const int rg = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel<YT>, dim3(rg, batch), dim3(256), 0, st, p);
+  }
+  CRG_CHECK_LAUNCH(ctx, "splitk_reduce");
+  return 0;
+}
+
 // Split-K factor: small-M problems (8x8 / 16x16 UNet levels, token GEMMs with few rows) launch far fewer
 // than 2 blocks per CU and stream long K; cut K so that ~512 blocks are in flight, keeping >= 8 k-tiles
 // per slice.  Costs one fp32 slab round trip + one extra launch, so only when the tile count is low.
@@ -1003,6 +1092,8 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
             (p.y_bs & 7) == 0 && ((uintptr_t)p.y & 15) == 0 &&
             (!p.res || ((p.ldr & 7) == 0 && (p.r_bs & 7) == 0 && ((uintptr_t)p.res & 15) == 0)) &&
             (!p.cvec || (p.cvec_ld & 3) == 0)) ? 1 : 0;
+  if (p.gstat && !p.pair && (p.splits == 1 || p.inred))
+    return crg_fail(ctx, -22, "gemm/conv: GroupNorm statistics come from the paired bf16 epilogue (N, ldy, ldr multiples of 8, 16-byte aligned y / residual, no GEGLU)");
   void (*kern)(GemmP);
   if constexpr (GLDS && sizeof(YT) == 2) kern = p.pair ? gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG, 1, true> : gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG>;
   else if constexpr (GLDS) kern = gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG>;
@@ -1141,12 +1232,7 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
         p.slab_row0 = row0;
         rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 2, 4, 1>(ctx, st, p, batch, Work{wk.flops * r / T, wk.bytes * r / T, 0, 0});
         if (rc) return rc;
-        const long total4 = (long)(p.M - row0) * (p.N >> 2);
-        const int rg = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
-        crg_prof_scope ps(ctx, st, CRG_K_SPLITK, (double)s2 * (p.M - row0) * p.N, (double)(p.M - row0) * p.N * (4.0 * s2 + sizeof(YT)));
-        hipLaunchKernelGGL(splitk_reduce_kernel<YT>, dim3(rg, 1), dim3(256), 0, st, p);
-        CRG_CHECK_LAUNCH(ctx, "splitk_reduce(tail)");
-        return 0;
+        return launch_reduce<YT>(ctx, st, p, 1);
       }
     }
     if (cfg == 3) rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 4, 2, 2>(ctx, st, p, batch, wk);
@@ -1156,14 +1242,7 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 2, 4, 1>(ctx, st, p, batch, wk);
   }
   if (rc) return rc;
-  if (p.splits > 1 && !p.inred) {
-    const long total4 = (long)p.M * (p.N >> 2);
-    const int rg = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
-    crg_prof_scope ps(ctx, st, CRG_K_SPLITK, (double)batch * p.splits * p.M * p.N,
-                      (double)batch * p.M * p.N * (4.0 * p.splits + sizeof(YT)));
-    hipLaunchKernelGGL(splitk_reduce_kernel<YT>, dim3(rg, batch), dim3(256), 0, st, p);
-    CRG_CHECK_LAUNCH(ctx, "splitk_reduce");
-  }
+  if (p.splits > 1 && !p.inred) return launch_reduce<YT>(ctx, st, p, batch);
   return 0;
 }
 
@@ -1174,6 +1253,7 @@ int launch_planes(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   constexpr int BN = 32 * WNT;
   constexpr size_t lds = (size_t)2 * 2 * (128 + BN) * 128 + 1024;
   p.zero_page = (const bf16*)ctx->zero_page;
+  if (p.gstat) return crg_fail(ctx, -22, "gemm/conv: GroupNorm statistics are a bf16-path feature");
   p.tiles_n = (p.N + BN - 1) / BN;
   p.tiles_m = (p.M + 127) / 128;
   p.splits = choose_splits(p, p.tiles_n * p.tiles_m, batch);
@@ -1233,6 +1313,8 @@ int launch_wnt(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
 
 template <bool CONV>
 int dispatch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, int a_dtype, int y_dtype, int prec, Work wk) {
+  if (p.gstat && !(prec == CRG_PREC_BF16 && a_dtype == CRG_BF16 && y_dtype == CRG_BF16 && batch == 1 && p.epi != CRG_EPI_GEGLU && (p.N & 7) == 0))
+    return crg_fail(ctx, -22, "gemm/conv: GroupNorm statistics need bf16 in / out, batch 1, N %% 8 == 0 and a plain epilogue");
   if (prec == CRG_PREC_BF16) {
     if (a_dtype == CRG_BF16 && y_dtype == CRG_BF16) return launch_wnt<1, bf16, bf16, CONV>(ctx, st, p, batch, wk);
     if (a_dtype == CRG_BF16 && y_dtype == CRG_F32) return launch_wnt<1, bf16, float, CONV>(ctx, st, p, batch, wk);
@@ -1275,6 +1357,8 @@ extern "C" int crg_gemm(crg_ctx* ctx, void* stream, const crg_gemm_args* a) {
   p.y = a->y; p.ldy = a->ldy; p.y_bs = a->y_bstride;
   p.M = a->M; p.N = a->N; p.K = a->K; p.epi = a->epilogue;
   p.cvec = nullptr; p.cvec_rows = 1; p.cvec_ld = 0; p.a_is_weight = a->a_is_weight;
+  p.gstat = a->gn_stats; p.gstat_plane = (long)((a->M + 31) / 32) * a->N;
+  if (a->gn_stats) CRG_REQUIRE(ctx, ((uintptr_t)a->gn_stats & 15) == 0, "gemm: gn_stats must be 16-byte aligned");
   const double flops = 2.0 * a->M * (double)a->N * a->K * a->batch;
   const double bytes = ((double)a->M * a->K * crg_dtype_size(a->a_dtype) + (double)a->N * a->K * 2 +
                         (double)a->M * a->N * crg_dtype_size(a->y_dtype) * (a->residual ? 2 : 1)) * a->batch;
@@ -1310,6 +1394,8 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
   p.cvec = a->cvec; p.cvec_rows = a->Ho * a->Wo; p.cvec_ld = a->cvec_ld ? a->cvec_ld : a->Cout;
   p.H = a->H; p.W = a->W; p.Ho = a->Ho; p.Wo = a->Wo; p.ks = a->ksize; p.stride = a->stride;
   p.pad_t = a->pad_t; p.pad_l = a->pad_l; p.up = a->upsample2x;
+  p.gstat = a->gn_stats; p.gstat_plane = (long)((p.M + 31) / 32) * p.N;
+  if (a->gn_stats) CRG_REQUIRE(ctx, ((uintptr_t)a->gn_stats & 15) == 0 && (a->Ho * a->Wo) % 32 == 0, "conv2d: gn_stats must be 16-byte aligned and Ho * Wo a multiple of 32");
   p.cm = (a->ksize == 3 && Ctot % 64 == 0) ? 1 : 0;  // must match crg_pack_weight's layout rule
   p.rowhalo = (p.cm && a->stride == 1 && a->pad_t == 1 && a->pad_l == 1 && a->Ho == Hv && a->Wo == Wv &&
                a->C1 % 8 == 0 && a->x_dtype == CRG_BF16 &&

@@ -2,6 +2,7 @@
 // block -> tile mapping, LDS swizzle, epilogues, counted vmcnt wait.
 #pragma once
 #include "crg_common.h"
+#include <type_traits>
 
 namespace crg_mm {
 
@@ -33,6 +34,10 @@ struct GemmP {
   unsigned* tile_cnt;   //     arrival counter per tile (zero on entry, reset by the last arriver)
   unsigned a_bytes, x2_bytes, w_bytes;  // conv: byte sizes of x, x2 and the packed weight (buffer descriptors of conv_ring.hip); 0 = unknown / >= 2 GiB
   int xg_m, xg_n, xg_s;  // XCD partition of the (m-tile, n-tile, k-slice) grid, product 8; xg_s == 0: legacy contiguous order
+  // GroupNorm statistics side channel (crg_*_args.gn_stats): per 32-row block and output channel, the sum and the sum of squares of
+  // the FINISHED (bf16-rounded) outputs: gstat[0][rb][n] / gstat[1][rb][n], plane stride gstat_plane floats.  Written by the paired
+  // epilogue or, for split-K launches, by the reduce kernel; null = none.
+  float* gstat; long gstat_plane;
 };
 
 constexpr int BM = 128;
@@ -205,63 +210,151 @@ __device__ __forceinline__ int unpair_col(int pos) {  // LDS row position within
 
 // r2[u][j] / r1[j] / bpre[i]: residual (16 bytes per tile pair, 8 for an odd last tile) and bias of this lane in the paired
 // mapping, fetched ahead of the K loop (has_res / has_bias say whether they were).
+// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), result in every lane: pure VALU (quad permutes, then the two row
+// mirrors), no LDS crossbar
+__device__ __forceinline__ float row16_sum(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+#endif
+  return v;
+}
+
 template <int WNT, int WMT>
 __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)[WNT][WMT], int m0, int n0, int wm, int wn, int frow,
                                                     int fq, int bz, const bf16x8 (&r2)[WNT / 2 > 0 ? WNT / 2 : 1][WMT],
                                                     const bf16x4 (&r1)[WMT], bool has_res, const f32x4 (&bpre)[WNT], bool has_bias) {
   bf16* Y = reinterpret_cast<bf16*>(p.y) + (long)bz * p.y_bs;
   const int nb = n0 + wn * (16 * WNT);
+  auto body = [&](auto STATSc) {
+    constexpr bool STATS = decltype(STATSc)::value;
+    constexpr int NG = WNT / 2 > 0 ? WNT / 2 : 1;
+    // STATS: per-channel sum / sum of squares of the rounded outputs over the wave's current 32-row block (two 16-row MFMA tiles)
+    float s1[STATS ? NG : 1][8], s2[STATS ? NG : 1][8], t1[4], t2[4];
+    const bool all_valid = m0 + wm * (16 * WMT) + 16 * WMT <= p.M;  // wave-uniform: the usual case, no per-row select
 #pragma unroll
-  for (int j = 0; j < WMT; ++j) {
-    const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
-    if (m >= p.M) continue;
-    const float brow = (p.bias_mode == CRG_BIAS_ROW) ? p.bias[m] : 0.f;
-    const float* cv = p.cvec ? p.cvec + (long)(m / p.cvec_rows) * p.cvec_ld : nullptr;
-    auto finish = [&](f32x4 v, int i, int n) {
-      if (has_bias) v += bpre[i];
-      else if (p.bias_mode == CRG_BIAS_ROW) v += brow;
-      if (p.epi == CRG_EPI_SILU) {
+    for (int j = 0; j < WMT; ++j) {
+      const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
+      const bool valid = m < p.M;
+      if constexpr (!STATS) {
+        if (!valid) continue;
+      } else if ((j & 1) == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = crg_silu_f(v[e]);
+        for (int u = 0; u < NG; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s1[u][e] = s2[u][e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t1[e] = t2[e] = 0.f;
       }
-      if (cv) v += *reinterpret_cast<const f32x4*>(cv + n);
-      return v;
-    };
+      const float brow = (p.bias_mode == CRG_BIAS_ROW) ? p.bias[valid ? m : 0] : 0.f;
+      const float* cv = p.cvec ? p.cvec + (long)((valid ? m : 0) / p.cvec_rows) * p.cvec_ld : nullptr;
+      auto finish = [&](f32x4 v, int i, int n) {
+        if (has_bias) v += bpre[i];
+        else if (p.bias_mode == CRG_BIAS_ROW) v += brow;
+        if (p.epi == CRG_EPI_SILU) {
 #pragma unroll
-    for (int u = 0; u < WNT / 2; ++u) {
-      const int n = nb + 32 * u + 8 * fq;
-      if (n >= p.N) continue;  // N % 8 == 0 in this mode: a group is in or out as a whole
-      f32x4 a = finish(acc[2 * u][j], 2 * u, n), b = finish(acc[2 * u + 1][j], 2 * u + 1, n + 4);
-      if (has_res) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          a[e] += (float)r2[u][j][e];
-          b[e] += (float)r2[u][j][4 + e];
+          for (int e = 0; e < 4; ++e) v[e] = crg_silu_f(v[e]);
         }
-      }
-      bf16x8 o;
+        if (cv) v += *reinterpret_cast<const f32x4*>(cv + n);
+        return v;
+      };
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e] = (bf16)a[e];
-        o[4 + e] = (bf16)b[e];
-      }
-      *reinterpret_cast<bf16x8*>(Y + (long)m * p.ldy + n) = o;
-    }
-    if constexpr (WNT & 1) {
-      const int n = nb + 16 * (WNT - 1) + 4 * fq;
-      if (n < p.N) {
-        f32x4 a = finish(acc[WNT - 1][j], WNT - 1, n);
+      for (int u = 0; u < WNT / 2; ++u) {
+        const int n = nb + 32 * u + 8 * fq;
+        if (n >= p.N) continue;  // N % 8 == 0 in this mode: a group is in or out as a whole (wave-uniform per 16-lane row)
+        f32x4 a = finish(acc[2 * u][j], 2 * u, n), b = finish(acc[2 * u + 1][j], 2 * u + 1, n + 4);
         if (has_res) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) a[e] += (float)r1[j][e];
+          for (int e = 0; e < 4; ++e) {
+            a[e] += (float)r2[u][j][e];
+            b[e] += (float)r2[u][j][4 + e];
+          }
         }
-        bf16x4 o;
+        bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16)a[e];
-        *reinterpret_cast<bf16x4*>(Y + (long)m * p.ldy + n) = o;
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (bf16)a[e];
+          o[4 + e] = (bf16)b[e];
+        }
+        if (valid) *reinterpret_cast<bf16x8*>(Y + (long)m * p.ldy + n) = o;
+        if constexpr (STATS) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = (all_valid || valid) ? (float)o[e] : 0.f;
+            s1[u][e] += f;
+            s2[u][e] = __builtin_fmaf(f, f, s2[u][e]);
+          }
+        }
+      }
+      if constexpr (WNT & 1) {
+        const int n = nb + 16 * (WNT - 1) + 4 * fq;
+        if (n < p.N) {
+          f32x4 a = finish(acc[WNT - 1][j], WNT - 1, n);
+          if (has_res) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += (float)r1[j][e];
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16)a[e];
+          if (valid) *reinterpret_cast<bf16x4*>(Y + (long)m * p.ldy + n) = o;
+          if constexpr (STATS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float f = (all_valid || valid) ? (float)o[e] : 0.f;
+              t1[e] += f;
+              t2[e] = __builtin_fmaf(f, f, t2[e]);
+            }
+          }
+        }
+      }
+      if constexpr (STATS) {
+        if ((j & 1) == 1) {
+          // fold the 16 rows held by the lanes of each DPP row (one lane group = one fq = one 8-channel column group), then lane
+          // frow == 0 of every group stores its channels' sums for row block rb
+          const int row0 = m0 + wm * (16 * WMT) + (j >> 1) * 32;
+          const long rb = row0 >> 5;
+          float* S1 = p.gstat + rb * p.N;
+          float* S2 = S1 + p.gstat_plane;
+#pragma unroll
+          for (int u = 0; u < WNT / 2; ++u) {
+            f32x4 a1, b1, a2, b2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              a1[e] = row16_sum(s1[u][e]);
+              b1[e] = row16_sum(s1[u][4 + e]);
+              a2[e] = row16_sum(s2[u][e]);
+              b2[e] = row16_sum(s2[u][4 + e]);
+            }
+            const int n = nb + 32 * u + 8 * fq;
+            if (frow == 0 && n < p.N && row0 < p.M) {
+              *reinterpret_cast<f32x4*>(S1 + n) = a1;
+              *reinterpret_cast<f32x4*>(S1 + n + 4) = b1;
+              *reinterpret_cast<f32x4*>(S2 + n) = a2;
+              *reinterpret_cast<f32x4*>(S2 + n + 4) = b2;
+            }
+          }
+          if constexpr (WNT & 1) {
+            f32x4 a1, a2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              a1[e] = row16_sum(t1[e]);
+              a2[e] = row16_sum(t2[e]);
+            }
+            const int n = nb + 16 * (WNT - 1) + 4 * fq;
+            if (frow == 0 && n < p.N && row0 < p.M) {
+              *reinterpret_cast<f32x4*>(S1 + n) = a1;
+              *reinterpret_cast<f32x4*>(S2 + n) = a2;
+            }
+          }
+        }
       }
     }
-  }
+  };
+  if (p.gstat) body(std::integral_constant<bool, true>{});
+  else body(std::integral_constant<bool, false>{});
 }
 
 template <int N>

@@ -134,7 +134,13 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const T* __restrict__ x, 
   const int t = threadIdx.x;
   const int gs = C / groups;
   const int C2 = C - C1;
-  {
+  if (n_chunks < 0) {
+    // statistics already final (gn_finalize_kernel): part = [N][groups] (mean, rstd)
+    if (t < groups) {
+      meanv[t] = part[((long)n * groups + t) * 2];
+      rstdv[t] = part[((long)n * groups + t) * 2 + 1];
+    }
+  } else {
     // 8 lanes per group sum the chunk partials in fp64, then a 3-step shuffle reduction
     const int g = t >> 3, sub = t & 7;
     double a = 0.0, b = 0.0;
@@ -229,6 +235,69 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const T* __restrict__ x, 
       g0[e] = f;
     }
     emit(g0, (long)r * C);
+  }
+}
+
+// ---- GroupNorm statistics from the PRODUCER's side channel -------------------------------------------------------------
+// The conv / GEMM that wrote x also wrote, per 32-row block and channel, the sum and the sum of squares of its (rounded) outputs
+// (crg_conv_args.gn_stats / crg_gemm_args.gn_stats: planes [2][rows / 32][C]).  One block per (sample, group) folds its group's
+// channels x the sample's row blocks in a fixed order (thread-strided fp32 partials, fp64 across the threads) into (mean, rstd):
+// the statistics pass over the tensor itself (gn_stats_kernel: a full read of x) disappears.  x2 != null: channels >= C1 of the
+// virtual concat come from the second producer's planes.  No float atomics, bitwise reproducible.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ st1, const float* __restrict__ st2, int C1, int C,
+                                                           int HW, int groups, long plane1, long plane2, float eps,
+                                                           float* __restrict__ mr) {
+  // block = (group g, sample n); thread = (row-block lane rl, channel cl of the group): a fixed channel per thread, no division
+  // in the loop, four independent row blocks (eight loads) in flight per thread
+  __shared__ double red[2][4];
+  const int g = blockIdx.x, n = blockIdx.y, t = threadIdx.x;
+  const int gs = C / groups, C2 = C - C1;
+  const int nrb = HW >> 5;
+  const int nrl = 256 / gs;          // row-block lanes (gs <= 128: at least two)
+  const int rl = t / gs, cl = t - rl * gs;
+  const int c = g * gs + cl;
+  float a = 0.f, b = 0.f;
+  if (rl < nrl) {
+    const bool second = c >= C1;
+    const int Cs = second ? C2 : C1;
+    const float* q = (second ? st2 + (c - C1) : st1 + c) + (long)n * nrb * Cs;
+    const long plane = second ? plane2 : plane1;
+    int rb = rl;
+    for (; rb + 3 * nrl < nrb; rb += 4 * nrl) {
+      const float* q0 = q + (long)rb * Cs;
+      const float* q1 = q0 + (long)nrl * Cs;
+      const float* q2 = q1 + (long)nrl * Cs;
+      const float* q3 = q2 + (long)nrl * Cs;
+      const float a0 = q0[0], a1 = q1[0], a2 = q2[0], a3 = q3[0];
+      const float b0 = q0[plane], b1 = q1[plane], b2 = q2[plane], b3 = q3[plane];
+      a += (a0 + a1) + (a2 + a3);
+      b += (b0 + b1) + (b2 + b3);
+    }
+    for (; rb < nrb; rb += nrl) {
+      a += q[(long)rb * Cs];
+      b += q[(long)rb * Cs + plane];
+    }
+  }
+  double da = a, db = b;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    da += __shfl_xor(da, o);
+    db += __shfl_xor(db, o);
+  }
+  if ((t & 63) == 0) {
+    red[0][t >> 6] = da;
+    red[1][t >> 6] = db;
+  }
+  __syncthreads();
+  if (t == 0) {
+    da = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    db = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double cnt = (double)HW * gs;
+    const double mean = da / cnt;
+    double var = db / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mr[((long)n * groups + g) * 2] = (float)mean;
+    mr[((long)n * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
 
@@ -539,6 +608,44 @@ extern "C" int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const vo
                              const float* beta, void* y, int N, int HW, int C, int groups, float eps, int fuse_silu,
                              int dtype) {
   return groupnorm_impl(ctx, stream, x, x2, C1, gamma, beta, y, nullptr, nullptr, N, HW, C, groups, eps, fuse_silu, dtype);
+}
+
+extern "C" int crg_groupnorm_pre(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* stats1,
+                                 const float* stats2, const float* gamma, const float* beta, void* y, int N, int HW, int C,
+                                 int groups, float eps, int fuse_silu, int dtype) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, N > 0 && HW > 0 && C > 0, "groupnorm_pre: empty input");
+  CRG_REQUIRE(ctx, dtype == CRG_BF16, "groupnorm_pre: the statistics side channel is a bf16-path feature (dtype %d)", dtype);
+  CRG_REQUIRE(ctx, groups > 0 && groups <= GN_MAX_GROUPS && C % groups == 0, "groupnorm_pre: groups=%d C=%d unsupported", groups, C);
+  CRG_REQUIRE(ctx, C % 8 == 0 && (C >> 3) <= 512, "groupnorm_pre: C=%d must be a multiple of 8 and <= 4096", C);
+  CRG_REQUIRE(ctx, HW % 32 == 0, "groupnorm_pre: HW=%d must be a multiple of the 32-row statistics blocks", HW);
+  CRG_REQUIRE(ctx, C / groups <= 128, "groupnorm_pre: group size %d unsupported (<= 128)", C / groups);
+  if (!x2) C1 = C;
+  CRG_REQUIRE(ctx, C1 > 0 && C1 <= C && C1 % 8 == 0 && (C - C1) % 8 == 0, "groupnorm_pre: concat split C1=%d of C=%d unsupported", C1, C);
+  CRG_REQUIRE(ctx, stats1 && (x2 == nullptr) == (stats2 == nullptr), "groupnorm_pre: one statistics buffer per input");
+  const long rbs = (long)N * (HW >> 5);
+  float* mr = (float*)crg_scratch(ctx, (size_t)N * groups * 2 * sizeof(float));
+  if (!mr) return crg_fail(ctx, -12, "groupnorm_pre: out of scratch");
+  hipStream_t st = (hipStream_t)stream;
+  const double elems = (double)N * HW * C;
+  {
+    crg_prof_scope ps(ctx, st, CRG_K_GN_STATS, 2.0 * rbs * C, 8.0 * rbs * C);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, st, stats1, stats2, C1, C, HW, groups, rbs * C1, rbs * (C - C1), eps, mr);
+  }
+  {
+    const int threads = (C >> 3) <= 256 ? 256 : 512;
+    int chunks = HW / 64;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 256) chunks = 256;
+    while ((long)chunks * N < 512 && chunks * 8 <= HW && chunks < 256) chunks *= 2;
+    const int rpc = (HW + chunks - 1) / chunks;
+    chunks = (HW + rpc - 1) / rpc;
+    crg_prof_scope ps(ctx, st, CRG_K_GN_APPLY, 5.0 * elems, elems * 4.0);
+    hipLaunchKernelGGL(gn_apply_kernel<bf16>, dim3(chunks, N), dim3(threads), 0, st, (const bf16*)x, (const bf16*)x2, C1, C, HW, groups, rpc, -1,
+                       mr, (const float*)nullptr, gamma, beta, eps, fuse_silu, (bf16*)y, (bf16*)nullptr, (bf16*)nullptr);
+  }
+  CRG_CHECK_LAUNCH(ctx, "groupnorm_pre");
+  return 0;
 }
 
 extern "C" int crg_groupnorm_split(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* gamma,

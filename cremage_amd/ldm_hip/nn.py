@@ -54,7 +54,7 @@ class Conv2d(nn.Conv2d):
         pad = self.padding[0] if isinstance(self.padding, tuple) else self.padding
         if ks == 1 and self.stride == (1, 1) and pad == 0 and self.in_channels > 8 and self.out_channels > 8 \
                 and not {"x2", "cvec", "upsample2x"} & set(k for k, v in fused.items() if v is not None and v is not False):
-            return ops.conv1x1(x, self.weight, self.bias, residual=fused.get("residual"))
+            return ops.conv1x1(x, self.weight, self.bias, residual=fused.get("residual"), gn_stats=bool(fused.get("gn_stats")))
         if "padding" in fused:
             pad = fused.pop("padding")
         return ops.conv2d(x, self.weight, self.bias, stride=self.stride[0], padding=pad, **fused)

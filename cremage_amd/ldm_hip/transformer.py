@@ -342,5 +342,6 @@ class SpatialTransformer(nn.Module):
         t = ops.linear(ops.tokens_of(xn), _eff(self, self.proj_in.weight, "proj_in"), self.proj_in.bias)
         for block in self.transformer_blocks:
             t = block(t, context=context)
-        y = ops.linear(t, _eff(self, self.proj_out.weight, "proj_out"), self.proj_out.bias, residual=x_in)
-        return ops.image_of(y, h, w)
+        # the block's output feeds the next ResBlock's GroupNorm: its statistics come out of this launch's epilogue
+        y = ops.linear(t, _eff(self, self.proj_out.weight, "proj_out"), self.proj_out.bias, residual=x_in, gn_hw=h * w)
+        return ops.image_of_stats(y, h, w)

@@ -69,7 +69,7 @@ class Upsample(nn.Module):
 
     def forward(self, x):
         assert x.shape[1] == self.channels
-        return self.conv(x, upsample2x=True)
+        return self.conv(x, upsample2x=True, gn_stats=True)  # feeds the next ResBlock's GroupNorm
 
 
 class Downsample(nn.Module):
@@ -87,7 +87,7 @@ class Downsample(nn.Module):
 
     def forward(self, x):
         assert x.shape[1] == self.channels
-        return self.op(x)
+        return self.op(x, gn_stats=True)  # feeds the next ResBlock's GroupNorm (and, as a skip, an output block's)
 
 
 class ResBlock(TimestepBlock):
@@ -133,13 +133,13 @@ class ResBlock(TimestepBlock):
         if emb_out is None:
             emb_out = self.emb_layers[1](ops.silu(emb), out_dtype=torch.float32)  # [N, Cout] fp32
         h = self.in_layers[0](x, silu=True, x2=x2)                              # GN32 + SiLU (one tensor even for a pair)
-        h = self.in_layers[2](h, cvec=emb_out)                                  # conv + bias + emb_out[:, :, None, None]
+        h = self.in_layers[2](h, cvec=emb_out, gn_stats=True)                   # conv + bias + emb_out[:, :, None, None]; statistics for out_layers[0]
         h = self.out_layers[0](h, silu=True)
         if isinstance(self.skip_connection, nn.Identity):
             skip = x if x2 is None else torch.cat([x, x2], dim=1)
         else:
             skip = self.skip_connection(x, x2=x2) if x2 is not None else self.skip_connection(x)
-        return self.out_layers[3](h, residual=skip)                             # conv + bias + skip(x)
+        return self.out_layers[3](h, residual=skip, gn_stats=True)              # conv + bias + skip(x); statistics for the next GroupNorm
 
 
 class UNetModel(nn.Module):

@@ -139,6 +139,30 @@ def clear_weight_cache():
     _f32_cache.clear()
 
 
+# ---------------------------------------------------------------------------------- GroupNorm statistics side channel
+# A conv / linear whose output feeds a GroupNorm can write, next to its output, the per-(32-row block, channel) sum and sum of
+# squares of what it stored (crg_conv_args.gn_stats / crg_gemm_args.gn_stats).  The buffer rides on the returned tensor object as
+# `_crg_gn = (stats, version, rows per sample)`; group_norm() uses it when the tensor has not been written since (`_version`:
+# ControlNet's in-place residual adds, cldm.py:57-65, invalidate it) and then skips its statistics pass over the tensor.
+GN_STATS = __import__("os").environ.get("CRG_GN_STATS", "1") != "0"  # dev knob: 0 = every GroupNorm computes its own statistics
+GN_STATS_MIN_HW = 512  # smaller images take the single-launch GroupNorm kernel, which reads the tensor once anyway
+
+
+def _gn_stats_buffer(rows: int, cols: int, hw: Optional[int], in_dtype, out_dtype, device) -> Optional[torch.Tensor]:
+    if not GN_STATS or not hw or hw % 32 or hw < GN_STATS_MIN_HW or rows % hw or cols % 8:
+        return None
+    if in_dtype != torch.bfloat16 or out_dtype != torch.bfloat16:
+        return None
+    return torch.empty((2, (rows + 31) // 32, cols), dtype=torch.float32, device=device)
+
+
+def _gn_stats_of(t: torch.Tensor, hw: int) -> Optional[torch.Tensor]:
+    g = getattr(t, "_crg_gn", None)
+    if g is None or g[1] != t._version or g[2] != hw or g[0].shape[2] != t.shape[1]:
+        return None
+    return g[0]
+
+
 def f32_vec(v: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     """fp32 contiguous view/copy of a bias / norm gain (kernels take fp32 vectors)."""
     if v is None:
@@ -269,6 +293,14 @@ def group_norm(x: torch.Tensor, weight, bias, groups: int, eps: float, silu: boo
                                              groups, eps, int(silu)), h, "crg_groupnorm_split")
         return hi, lo
     y = empty_image(n, c, hh, ww, x.dtype, x.device)
+    if x.dtype == torch.bfloat16:
+        # statistics handed over by the producer(s) of x (and x2): no statistics pass over the tensor
+        st1 = _gn_stats_of(x, hh * ww)
+        st2 = _gn_stats_of(x2, hh * ww) if x2 is not None else None
+        if st1 is not None and (x2 is None or st2 is not None):
+            L.check(L.load().crg_groupnorm_pre(h, _st(), _p(x), _p(x2), c1, _p(st1), _p(st2), _p(f32_vec(weight)), _p(f32_vec(bias)), _p(y),
+                                               n, hh * ww, c, groups, eps, int(silu), L.BF16), h, "crg_groupnorm_pre")
+            return y
     L.check(L.load().crg_groupnorm(h, _st(), _p(x), _p(x2), c1, _p(f32_vec(weight)), _p(f32_vec(bias)), _p(y), n, hh * ww, c,
                                    groups, eps, int(silu), _act_dt(x)), h, "crg_groupnorm")
     return y
@@ -304,9 +336,10 @@ def _gemm(h, **kw):
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-           act: Optional[str] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+           act: Optional[str] = None, out_dtype: Optional[torch.dtype] = None, gn_hw: Optional[int] = None) -> torch.Tensor:
     """y = act(x @ weight^T + bias) + residual over the last dim of x.
-    weight: [N, K] (nn.Linear) or [N, K, 1, 1] (1x1 conv).  act: None | 'silu' | 'geglu'."""
+    weight: [N, K] (nn.Linear) or [N, K, 1, 1] (1x1 conv).  act: None | 'silu' | 'geglu'.
+    gn_hw: y (as an image of gn_hw tokens per sample) feeds a GroupNorm - emit its statistics side channel (bf16 only, see above)."""
     _need_cuda(x, weight, bias, residual)
     x = x.contiguous()
     K = x.shape[-1]
@@ -333,12 +366,16 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         if residual.shape != y.shape or residual.dtype != y.dtype:
             raise L.CrgError("linear: residual must match the output in shape and dtype")
     h = _h(x)
+    stats = _gn_stats_buffer(M, N, gn_hw, x.dtype, out_dtype, x.device) if not geglu else None
     _gemm(h, a=x.data_ptr(), lda=K, a_bstride=0, w=hi.data_ptr(), ldw=K, w_bstride=0, w_lo=lo.data_ptr() if lo is not None else None,
           bias=b.data_ptr() if b is not None else None, bias_mode=L.BIAS_COL if b is not None else L.BIAS_NONE,
           residual=residual.data_ptr() if residual is not None else None, ldr=n_out, r_bstride=0,
           y=y.data_ptr(), ldy=n_out, y_bstride=0, M=M, N=N, K=K, batch=1,
           epilogue={None: L.EPI_NONE, "silu": L.EPI_SILU, "geglu": L.EPI_GEGLU}[act],
-          a_dtype=_act_dt(x), y_dtype=_DT[out_dtype], prec=_prec(x), a_is_weight=0, a_lo=None)
+          a_dtype=_act_dt(x), y_dtype=_DT[out_dtype], prec=_prec(x), a_is_weight=0, a_lo=None,
+          gn_stats=stats.data_ptr() if stats is not None else None)
+    if stats is not None:
+        y._crg_gn_pending = stats  # the caller that shapes y into an image attaches it (image_of_stats)
     return y
 
 
@@ -459,12 +496,13 @@ def split_bf16(x: torch.Tensor):
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, padding=1,
            upsample2x: bool = False, x2: Optional[torch.Tensor] = None, cvec: Optional[torch.Tensor] = None,
-           residual: Optional[torch.Tensor] = None, x_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
+           residual: Optional[torch.Tensor] = None, x_lo: Optional[torch.Tensor] = None, gn_stats: bool = False) -> torch.Tensor:
     """Implicit-GEMM conv over channels-last images.
     padding: int (symmetric) or (top, left, bottom, right).  `upsample2x`: nearest-2x of the input is
     folded into the gather.  `x2`: second half of a virtual channel concat.  `cvec` fp32 [N, Cout] is
     added per sample (timestep embedding); `residual` is added after.  `x_lo`: x is the bf16 hi plane of a pre-split
-    fp32 activation and x_lo its lo plane (group_norm(split=True) / split_bf16): fp32-class conv with fp32 output."""
+    fp32 activation and x_lo its lo plane (group_norm(split=True) / split_bf16): fp32-class conv with fp32 output.
+    `gn_stats`: the output feeds a GroupNorm - emit its statistics side channel where the path supports it (bf16, see above)."""
     _need_cuda(x, weight, bias, x2, cvec, residual, x_lo)
     x = to_channels_last(x)
     if x_lo is not None:
@@ -515,18 +553,32 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
                    cvec_ld=cvec.stride(0) if cvec is not None else 0, residual=_p(residual).value, y=y.data_ptr(), N=n, H=hh, W=ww, Cout=cout, Ho=ho, Wo=wo, ksize=ks, stride=stride,
                    pad_t=pt, pad_l=pl, upsample2x=int(upsample2x), x_dtype=_act_dt(x), y_dtype=_act_dt(y),
                    prec=L.PREC_BF16X3 if planes else _prec(x), x_lo=x_lo.data_ptr() if planes else None)
+    stats = _gn_stats_buffer(n * ho * wo, cout, ho * wo, x.dtype, y.dtype, x.device) if (gn_stats and not planes) else None
+    if stats is not None:
+        a.gn_stats = stats.data_ptr()
     h = _h(x)
     L.check(L.load().crg_conv2d(h, _st(), C.byref(a)), h, "crg_conv2d")
+    if stats is not None:
+        y._crg_gn = (stats, y._version, ho * wo)
     return y
 
 
-def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias=None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias=None, residual: Optional[torch.Tensor] = None, gn_stats: bool = False) -> torch.Tensor:
     """1x1 conv on a channels-last image == linear over its token view (no copy either way)."""
     x = to_channels_last(x)
     n, c, hh, ww = x.shape
     res_t = tokens_of(to_channels_last(residual)) if residual is not None else None
-    y = linear(tokens_of(x), weight, bias, residual=res_t)
-    return image_of(y, hh, ww)
+    y = linear(tokens_of(x), weight, bias, residual=res_t, gn_hw=hh * ww if gn_stats else None)
+    return image_of_stats(y, hh, ww)
+
+
+def image_of_stats(t: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """image_of() that carries the GroupNorm statistics `linear(..., gn_hw=h*w)` produced over to the image view."""
+    img = image_of(t, h, w)
+    st = getattr(t, "_crg_gn_pending", None)
+    if st is not None:
+        img._crg_gn = (st, img._version, h * w)
+    return img
 
 
 # ---------------------------------------------------------------------------------- attention

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CRG_VERSION 100
+#define CRG_VERSION 101
 
 typedef struct crg_ctx crg_ctx;
 
@@ -99,6 +99,15 @@ int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const void* x2, int
 int crg_groupnorm_split(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* gamma,
                         const float* beta, void* y_hi, void* y_lo, int N, int HW, int C, int groups, float eps,
                         int fuse_silu);
+/* GroupNorm (+SiLU) whose STATISTICS come from the producer of x (and of x2): the conv / GEMM launch that wrote the tensor also wrote
+ * `gn_stats` (crg_conv_args / crg_gemm_args): per 32-row block and channel the sum and the sum of squares of its rounded outputs,
+ * planes [2][N * HW / 32][C1].  This call folds them per (sample, group) - one tiny launch instead of a read of the whole tensor -
+ * and applies the normalisation.  Same result as crg_groupnorm up to the summation order of the statistics (fp32 partials of 32
+ * values, fp64 fold).  bf16 only; HW % 32 == 0.  Reference call sites as crg_groupnorm (util.py:214-216, openaimodel.py:205-209,
+ * 229-236: the GroupNorm32 + SiLU in front of each ResBlock conv).  stats2 pairs with x2 (virtual concat). */
+int crg_groupnorm_pre(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* stats1,
+                      const float* stats2, const float* gamma, const float* beta, void* y, int N, int HW, int C,
+                      int groups, float eps, int fuse_silu, int dtype);
 /* fp32 tensor -> the same two bf16 planes (n elements, n % 8 == 0): for fp32-class convs whose input does not come from a
  * GroupNorm (the VAE's Upsample / Downsample convs on the residual stream, model.py:60-64,79-86). */
 int crg_split_bf16(crg_ctx* ctx, void* stream, const void* x, void* hi, void* lo, int64_t n);
@@ -158,6 +167,10 @@ typedef struct {
   int a_dtype, y_dtype, prec;
   int a_is_weight;   /* BF16X3 only: `a` is a packed weight (hi plane) and a_lo its lo plane */
   const void* a_lo;
+  /* optional GroupNorm statistics side channel (bf16 in / out, batch 1, N % 8 == 0, plain epilogue): fp32 [2][ceil(M / 32)][N],
+   * plane 0 = per 32-row block and column the sum of the rounded outputs y, plane 1 the sum of their squares (consumed by
+   * crg_groupnorm_pre when y - e.g. proj_out + residual, attention.py:1049-1057 - feeds the next ResBlock's GroupNorm) */
+  float* gn_stats;
 } crg_gemm_args;
 int crg_gemm(crg_ctx* ctx, void* stream, const crg_gemm_args* args);
 
@@ -184,6 +197,9 @@ typedef struct {
   const void* x_lo;                 /* BF16X3 with PRE-SPLIT activations: `x` is the bf16 hi plane, `x_lo` the bf16 lo plane
                                        (same layout; written by crg_groupnorm_split / crg_split_bf16); x_dtype = CRG_BF16,
                                        y_dtype = CRG_F32; NULL otherwise */
+  float* gn_stats;                  /* optional GroupNorm statistics side channel of y (see crg_gemm_args.gn_stats; M = N * Ho * Wo rows,
+                                       Ho * Wo % 32 == 0): the conv in front of a GroupNorm (openaimodel.py:208 -> :229-231, :234 -> the
+                                       next block's :205-207) hands it the statistics, so the tensor is not read once more for them */
 } crg_conv_args;
 int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* args);
 

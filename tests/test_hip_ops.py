@@ -452,6 +452,77 @@ def test_group_norm_production_shapes(N, C1, C2, hw, silu):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
 
 
+def _stats_ref(y, hw):
+    """per 32-row block and channel: sum / sum of squares of a channels-last bf16 image, as the producers' side channel defines it"""
+    n, c, hh, ww = y.shape
+    t = y.permute(0, 2, 3, 1).reshape(n * hh * ww // 32, 32, c).float()
+    return torch.stack([t.sum(1), (t * t).sum(1)])
+
+
+@pytest.mark.parametrize("case", ["conv_unsplit", "conv_splitk", "conv_pairless_tail", "linear_cfgA", "linear_cfgC", "linear_cfgD", "conv_stride2"])
+def test_gn_stats_side_channel(case):
+    """The GroupNorm statistics a conv / linear writes next to its output (crg_*_args.gn_stats) equal the sums over its STORED bf16
+    output, on every code path that writes them: the paired epilogue (three tile configurations, the 256-pixel ring conv), the
+    split-K reduce kernel, a stride-2 conv; and group_norm() on such a tensor equals group_norm() with its own statistics pass."""
+    from cremage_amd import ops
+    dev = _dev()
+    if case.startswith("conv"):
+        N, Cin, Cout, hw, stride = {"conv_unsplit": (8, 64, 320, 64, 1), "conv_splitk": (2, 640, 640, 32, 1), "conv_pairless_tail": (9, 64, 320, 64, 1),
+                                    "conv_stride2": (4, 128, 320, 64, 2)}[case]
+        x = rnd(N, Cin, hw, hw, seed=200)
+        w, b = rnd(Cout, Cin, 3, 3, seed=201, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=202)
+        cv = rnd(N, Cout, seed=203).to(dev)
+        ho = hw // stride
+        r = rnd(N, Cout, ho, ho, seed=204)
+        y = ops.conv2d(nhwc(x, BF), w.to(dev), b.to(dev), stride=stride, padding=1, cvec=cv, residual=nhwc(r, BF), gn_stats=True)
+        ref = F.conv2d(q(x, BF), q(w, BF), b, stride=stride, padding=1) + cv.cpu()[:, :, None, None] + q(r, BF)
+        C = Cout
+    else:
+        M, Nn, K, hw = {"linear_cfgA": (32768, 320, 320, 4096), "linear_cfgC": (2048, 1280, 1280, 1024), "linear_cfgD": (8192, 640, 640, 1024)}[case]
+        x, w, b, r = rnd(M, K, seed=210), rnd(Nn, K, seed=211, scale=K ** -0.5), rnd(Nn, seed=212), rnd(M, Nn, seed=213)
+        side = int(hw ** 0.5)
+        t = ops.linear(x.to(dev).to(BF).view(M // hw, hw, K), w.to(dev), b.to(dev), residual=r.to(dev).to(BF).view(M // hw, hw, Nn), gn_hw=hw)
+        y = ops.image_of_stats(t, side, side)
+        ref = (F.linear(q(x, BF), q(w, BF), b) + q(r, BF)).view(M // hw, side, side, Nn).permute(0, 3, 1, 2)
+        C = Nn
+    check(y, ref, BF, case)
+    g = getattr(y, "_crg_gn", None)
+    assert g is not None, "the producer did not hand over statistics"
+    st = g[0].cpu()
+    want = _stats_ref(y.float().cpu(), g[2])
+    assert st.shape == want.shape
+    assert (st[0] - want[0]).abs().max().item() < 1e-3 * max(1.0, want[0].abs().max().item())
+    assert (st[1] - want[1]).abs().max().item() < 1e-4 * want[1].abs().max().item()
+    gam, bet = (1 + 0.1 * rnd(C, seed=220)).to(dev), (0.1 * rnd(C, seed=221)).to(dev)
+    fast = ops.group_norm(y, gam, bet, 32, 1e-5, silu=True)
+    again = ops.group_norm(y, gam, bet, 32, 1e-5, silu=True)
+    assert torch.equal(fast, again)  # fixed-order folds: bitwise reproducible
+    plain = ops.group_norm(y.clone(memory_format=torch.preserve_format), gam, bet, 32, 1e-5, silu=True)  # a clone carries no statistics
+    refn = F.silu(F.group_norm(y.float().cpu(), 32, gam.cpu(), bet.cpu(), 1e-5))
+    check(fast, refn, BF, case + " gn(pre)")
+    assert (fast.float() - plain.float()).abs().max().item() <= 2 ** -6 * refn.abs().max().item()
+    # written since: the statistics are stale and must not be used
+    y.add_(1.0)
+    assert ops._gn_stats_of(y, g[2]) is None
+    check(ops.group_norm(y, gam, bet, 32, 1e-5, silu=True), F.silu(F.group_norm(y.float().cpu(), 32, gam.cpu(), bet.cpu(), 1e-5)), BF, case + " stale")
+
+
+def test_gn_stats_concat_pair():
+    """virtual concat of two producers' outputs (the output blocks' GroupNorm over [h, skip], openaimodel.py:808): groups that
+    straddle the two tensors take their channels from both side channels (960 = 640 + 320 channels: group size 30)."""
+    from cremage_amd import ops
+    dev = _dev()
+    xa, xb = rnd(2, 64, 32, 32, seed=230), rnd(2, 64, 32, 32, seed=231)
+    wa, wb = rnd(640, 64, 3, 3, seed=232, scale=0.05), rnd(320, 64, 3, 3, seed=233, scale=0.05)
+    ya = ops.conv2d(nhwc(xa, BF), wa.to(dev), None, padding=1, gn_stats=True)
+    yb = ops.conv2d(nhwc(xb, BF), wb.to(dev), None, padding=1, gn_stats=True)
+    assert getattr(ya, "_crg_gn", None) is not None and getattr(yb, "_crg_gn", None) is not None
+    gam, bet = (1 + 0.1 * rnd(960, seed=234)).to(dev), (0.1 * rnd(960, seed=235)).to(dev)
+    got = ops.group_norm(ya, gam, bet, 32, 1e-5, silu=True, x2=yb)
+    ref = F.silu(F.group_norm(torch.cat([ya.float().cpu(), yb.float().cpu()], 1), 32, gam.cpu(), bet.cpu(), 1e-5))
+    check(got, ref, BF, "gn(pre) concat")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_group_norm_concat(dtype):
     from cremage_amd import ops
