@@ -227,3 +227,27 @@ def txt2img_sdxl_facefix(eng, c: dict, uc: dict, boxes, *, steps: int = 30, cfg_
         for i, (t, l, sz) in enumerate(boxes):
             out[i, :, t:t + sz, l:l + sz] = F.interpolate(fixed[i:i + 1], size=(sz, sz), mode="bilinear", align_corners=False)[0]
     return out, first, fixed
+
+
+@torch.no_grad()
+def face_fix_sdxl(eng, images: torch.Tensor, faces, c: dict, uc: dict, *, steps: int = 30, strength: float = 0.3, cfg_scale: float = 5.0,
+                  target_edge_len: int = 1024, enc_noise: Optional[torch.Tensor] = None, fwd_noise: Optional[torch.Tensor] = None):
+    """The auto-face-fix second pass with the REFERENCE's host-side glue (cremage_amd.postprocess: buffer / clamp / aspect-preserving
+    Lanczos resize / white padding / un-pad / resize back / paste, face_detector_engine.py:152-288) around the UNet re-entry
+    (`img2img_sdxl`, strength 0.3).  images [b,3,H,W] in [0,1]; faces[i] = list of (x, y, w, h) boxes of image i (the detector is out
+    of scope).  Differences from the reference that remain: plain paste instead of cv.seamlessClone (no OpenCV here), and one
+    conditioning row per image instead of a gender-prefixed prompt.  Returns [b,3,H,W] in [0,1] on the images' device."""
+    from . import postprocess as PP
+    out = []
+    for i in range(images.shape[0]):
+        ci = {k: v[i:i + 1] for k, v in c.items()}
+        uci = {k: v[i:i + 1] for k, v in uc.items()}
+
+        def i2i(x):
+            y, _ = img2img_sdxl(eng, x.to(images.device), ci, uci, steps=steps, strength=strength, cfg_scale=cfg_scale,
+                                enc_noise=enc_noise[i:i + 1] if enc_noise is not None else None,
+                                fwd_noise=fwd_noise[i:i + 1] if fwd_noise is not None else None)
+            return y
+        pil = PP.face_fix(PP.unit_tensor_to_pil(images[i]), faces[i], i2i, target_edge_len)
+        out.append((PP.pil_to_unit_tensor(pil)[0] + 1.0) * 0.5)
+    return torch.stack(out).to(images.device)
