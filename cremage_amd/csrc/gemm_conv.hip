@@ -1047,9 +1047,11 @@ inline int choose_splits(const GemmP& p, int tiles, int batch) {
     }
     return s;
   }
-  s = (int)((512 + blocks - 1) / blocks);
+  static const int tgt = getenv("CRG_SPLIT_BLOCKS") ? atoi(getenv("CRG_SPLIT_BLOCKS")) : 512;  // dev knob: blocks aimed at by the K cut
+  static const int smax = getenv("CRG_SPLIT_MAX") ? atoi(getenv("CRG_SPLIT_MAX")) : 16;          // dev knob: most K slices
+  s = (int)((tgt + blocks - 1) / blocks);
   if (s > nk / 8) s = nk / 8;
-  if (s > 16) s = 16;
+  if (s > smax) s = smax;
   return s < 2 ? 1 : s;
 }
 
@@ -1139,8 +1141,11 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
 // Tile / pipeline configuration of the LDS-DMA kernel, by how many blocks the problem yields (256 CUs):
 //   A  128 x BN tile, 4 waves, 2-deep ring  : >= ~1.5 blocks per CU (after split-K); two blocks share a CU and hide each
 //                                             other's latencies
-//   D   64 x BN tile, 4 waves, 2-deep ring  : 192..383 tiles of 128 rows and a short K: twice the blocks -> two per CU again
-//                                             (4096x1280x1280: A 26.7, 8-wave 128-row variant 25.5, D 23.6 us)
+//   D   64 x BN tile, 4 waves, 2-deep ring  : 192..1023 tiles of 128 rows (GEGLU epilogues: 192..383) and a short K: twice the blocks
+//                                             (4096x1280x1280: A 26.7, 8-wave 128-row variant 25.5, D 23.6 us).  Round 3, device time
+//                                             inside a captured graph (tools/lin_probe.py): 32768x320x320 + residual 25.8 (A) -> 22.4,
+//                                             8192x1920x640 41.6 -> 35.3, 2048x3840x1280 41.8 -> 34.6, 32768x320x1280 49.8 -> 45.3 us; the
+//                                             GEGLU GEMMs (128-wide tiles, heavy epilogue) keep A: 8192x5120x640 82 (A) vs 89 (D)
 //   C   64 x BN tile, 8 waves (two k-groups, folded through LDS), 4-deep ring : < 192 tiles (16x16 / 8x8 token GEMMs): one
 //                                             block per CU at most, so the waves and the ring depth come from inside the block
 //                                             (2048x1280x1280: A 24.7, C 16.7 us)
@@ -1158,8 +1163,10 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   int cfg = 1;
   if (GLDS && p.splits == 1) {
     const long blocks = (long)p.tiles_m * p.tiles_n * batch;
+    static const int d_max = getenv("CRG_GEMM_D_MAX") ? atoi(getenv("CRG_GEMM_D_MAX")) : 1024;     // dev knob: 64-row tiles below this many 128-row tiles (plain epilogues)
+    static const int d_max_g = getenv("CRG_GEMM_D_MAXG") ? atoi(getenv("CRG_GEMM_D_MAXG")) : 384;  // ... GEGLU epilogues
     if (blocks < 192) cfg = 3;
-    else if (blocks < 384) cfg = 4;
+    else if (blocks < ((CONV || p.epi == CRG_EPI_GEGLU) ? d_max_g : d_max)) cfg = 4;  // convs keep 384: above it they run on the row-halo / ring kernels
   }
   if (GLDS && force) cfg = force;
   if (cfg == 3 || cfg == 4) {

@@ -128,8 +128,9 @@ class TensorKeyedCache:
         TensorKeyedCache.generation += 1
 
 
-_ROWRES = __import__("os").environ.get("CRG_ROWRES", "0") != "0"  # dev knob: 1 = route plain K = 320 GEMMs with >= 16384 rows to the row-resident kernel
-#                                                               (measured on the UNet call: 10.71 ms routed vs 10.61 ms on crg_gemm - off)
+_ROWRES = __import__("os").environ.get("CRG_ROWRES", "1") != "0"  # dev knob: 0 = never route plain K = 320 GEMMs to the row-resident kernel.
+# Round 3, device time inside a captured graph (tools/lin_probe.py), 32768 x 320 x 320: WITHOUT a residual (proj_in) 16.7 us row-resident vs
+# 19.3 us on crg_gemm's 64-row tiles; WITH a residual 22.0 vs 22.4 (equal) - so only the residual-free ones are routed.
 _pack_cache = TensorKeyedCache()
 _f32_cache = TensorKeyedCache()
 
@@ -351,7 +352,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     out_dtype = out_dtype or x.dtype
     if split and out_dtype != torch.float32:
         raise L.CrgError("linear: fp32 (BF16X3) inputs produce fp32 outputs")
-    if _ROWRES and act is None and out_dtype == torch.bfloat16 and M >= 16384 and ln_linear_ok(x, weight):
+    if _ROWRES and act is None and residual is None and gn_hw is None and out_dtype == torch.bfloat16 and M >= 16384 and ln_linear_ok(x, weight):
         # K = 320 with many rows (the 64x64 level's to_out / proj_in / proj_out): the row-resident kernel without its LayerNorm
         return ln_linear(x, None, None, 0.0, weight, bias, residual=residual)
     geglu = act == "geglu"
