@@ -279,9 +279,11 @@ __global__ __launch_bounds__(256 * KG) void gemm_kernel(GemmP p) {
 // CU (2 x 74 KB); grids that cannot put two blocks on a CU anyway run STAGES = 4 (147 KB) so that a lone block still
 // covers the ~1.5 us global -> LDS latency.
 
-template <int WNT, typename YT, bool CONV, int STAGES, int WMT, int KG, int NS = 1, bool PAIR = false>
-__global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
+// (launch bounds: configuration A - 128-row tiles, 4 waves, 2 stages - is built for TWO blocks per CU: its register budget is 256)
+template <int WNT, typename YT, bool CONV, int STAGES, int WMT, int KG, int NS = 1, bool PAIR = false, bool GST = false>
+__global__ __launch_bounds__(256 * KG, (KG == 1 && WMT == 4 && STAGES == 2 && NS == 1) ? 2 : 1) void gemm_glds_kernel(GemmP p) {
   static_assert(!PAIR || (sizeof(YT) == 2 && NS == 1), "paired columns: bf16 output, single-plane operands");
+  static_assert(!GST || PAIR, "GroupNorm statistics come from the paired epilogue");  // GST: the instantiation that emits them (p.gstat set)
   // NS = 2: split-bf16 (fp32-class) operands - the activations arrive pre-split as two bf16 planes (hi = bf16(x),
   // lo = bf16(x - hi), written by the producing GroupNorm / split pass), the weights as their two packed planes; all four
   // are staged by LDS-DMA and every fragment pair costs three MFMAs (hi*hi + hi*lo + lo*hi).
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_glds_kernel(GemmP p) {
       for (int j = 0; j < WMT; ++j) acc[i][j] += red[(i * WMT + j) * 64];
   }
   if constexpr (PAIR) {
-    gemm_epilogue_pairs<WNT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, bz, r2, r1, pre_res, bpre, pre_bias);
+    gemm_epilogue_pairs<WNT, WMT, GST ? 1 : 0>(p, acc, m0, n0, wm, wn, frow, fq, bz, r2, r1, pre_res, bpre, pre_bias);
   } else {
     gemm_epilogue<WNT, YT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid, rres, pre_res, bpre, pre_bias);
   }
@@ -1031,7 +1033,9 @@ inline int choose_splits(const GemmP& p, int tiles, int batch) {
   // two when it is long enough to amortise the slab pass (measured: 8x32x32 640->640 conv 112 -> 89 us, 1280->640 203 -> 137 us;
   // K = 2560 GEMMs lose 5 %, hence the nk bound)
   // short K (nk < 24) is not split: measured slower than the 64-row / 8-wave configuration on the unsplit problem
-  if (blocks >= 512 || nk < 24 || (blocks >= 256 && nk < 64)) return 1;
+  // (128..255 tiles with a K of 24..63 k-tiles - the 16x16-level 1x1 skip convs over a concat, 2048 x 1280 x 1920 / 2560 - are faster
+  // unsplit on the 64-row / 8-wave configuration: 30.3 -> 24.0 us and 33.6 -> 30.5 us, tools/c1_probe.py, round 3)
+  if (blocks >= 512 || nk < 24 || (blocks >= 128 && nk < 64)) return 1;
   int s;
   if (blocks >= 256) {
     // one to two blocks per CU and a long K: among 2..4 slices take the one whose blocks fill whole rounds of 512 best
@@ -1097,7 +1101,9 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   if (p.gstat && !p.pair && (p.splits == 1 || p.inred))
     return crg_fail(ctx, -22, "gemm/conv: GroupNorm statistics come from the paired bf16 epilogue (N, ldy, ldr multiples of 8, 16-byte aligned y / residual, no GEGLU)");
   void (*kern)(GemmP);
-  if constexpr (GLDS && sizeof(YT) == 2) kern = p.pair ? gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG, 1, true> : gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG>;
+  if constexpr (GLDS && sizeof(YT) == 2)
+    kern = p.pair ? ((p.gstat && p.splits == 1) ? gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG, 1, true, true> : gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG, 1, true>)
+                  : gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG>;
   else if constexpr (GLDS) kern = gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG>;
   else kern = gemm_kernel<WNT, NSPLIT, AT, YT, CONV, NSPLIT>;  // split-bf16: 8 waves (two k-groups)
   size_t lds_bytes = lds;
@@ -1166,7 +1172,7 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     static const int d_max = getenv("CRG_GEMM_D_MAX") ? atoi(getenv("CRG_GEMM_D_MAX")) : 1024;     // dev knob: 64-row tiles below this many 128-row tiles (plain epilogues)
     static const int d_max_g = getenv("CRG_GEMM_D_MAXG") ? atoi(getenv("CRG_GEMM_D_MAXG")) : 384;  // ... GEGLU epilogues
     if (blocks < 192) cfg = 3;
-    else if (blocks < ((CONV || p.epi == CRG_EPI_GEGLU) ? d_max_g : d_max)) cfg = 4;  // convs keep 384: above it they run on the row-halo / ring kernels
+    else if (blocks < (((CONV && p.ks != 1) || p.epi == CRG_EPI_GEGLU) ? d_max_g : d_max)) cfg = 4;  // 3x3 convs keep 384: above it they run on the row-halo / ring kernels
   }
   if (GLDS && force) cfg = force;
   if (cfg == 3 || cfg == 4) {

@@ -222,7 +222,12 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <int WNT, int WMT>
+// SM: 0 = this instantiation never emits GroupNorm statistics, 1 = always (p.gstat is set), 2 = decided at run time.  The statistics
+// path keeps ~40 more values live; compiled into the two-blocks-per-CU GEMM kernel as a runtime branch it pushed that kernel from
+// 160 to 214 VGPRs (+ 80 accumulators: past 256, i.e. ONE block per CU for every GEMM, statistics or not) - that kernel therefore
+// takes it as a template parameter; the one-block-per-CU conv kernels, whose register budget is fixed by their launch bounds, keep
+// the runtime form (no extra instantiations, no spills).
+template <int WNT, int WMT, int SM = 2>
 __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)[WNT][WMT], int m0, int n0, int wm, int wn, int frow,
                                                     int fq, int bz, const bf16x8 (&r2)[WNT / 2 > 0 ? WNT / 2 : 1][WMT],
                                                     const bf16x4 (&r1)[WMT], bool has_res, const f32x4 (&bpre)[WNT], bool has_bias) {
@@ -353,7 +358,9 @@ __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)
       }
     }
   };
-  if (p.gstat) body(std::integral_constant<bool, true>{});
+  if constexpr (SM == 1) body(std::integral_constant<bool, true>{});
+  else if constexpr (SM == 0) body(std::integral_constant<bool, false>{});
+  else if (p.gstat) body(std::integral_constant<bool, true>{});
   else body(std::integral_constant<bool, false>{});
 }
 

@@ -23,11 +23,13 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--graph", action="store_true", help="device time inside a captured hipGraph (tools/gt.py) instead of eager launches "
+                                                         "bracketed by events (which are host-bound below ~15 us)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     ldm = P.build_synthetic_ldm(device=dev, seed=1)
     calls = []
-    orig = {n: getattr(ops, n) for n in ["conv2d", "linear", "linear_transposed", "attention", "group_norm", "layer_norm"]}
+    orig = {n: getattr(ops, n) for n in ["conv2d", "linear", "linear_transposed", "attention", "attention_rows_v", "group_norm", "layer_norm", "ln_linear"]}
 
     def wrap(name):
         f = orig[name]
@@ -74,13 +76,20 @@ def main():
         if name in ("linear", "linear_transposed"):
             x, w = args[0], args[1]
             return 2.0 * (x.numel() // x.shape[-1]) * w.shape[0] * w[0].numel()
+        if name == "ln_linear":
+            x, w = args[0], args[4]
+            return 2.0 * (x.numel() // x.shape[-1]) * w.shape[0] * w[0].numel()
         if name == "attention":
             q, k = args[0], args[1]
             return 4.0 * q.shape[0] * q.shape[1] * args[4] * q.shape[2]
+        if name == "attention_rows_v":
+            q, k = args[0], args[1]
+            return 4.0 * q.shape[0] * q.shape[1] * k.shape[1] * q.shape[2]
         return 0.0
 
     def nbytes(name, args, kw, out):
-        tot = out.numel() * out.element_size()
+        outs = out if isinstance(out, tuple) else (out,)
+        tot = sum(o.numel() * o.element_size() for o in outs)
         for v in list(args) + list(kw.values()):
             if torch.is_tensor(v):
                 tot += v.numel() * v.element_size()
@@ -92,13 +101,17 @@ def main():
             f = orig[name]
             out = f(*args, **kw)
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(a.reps):
-                f(*args, **kw)
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / a.reps
+            if a.graph:
+                from tools.gt import graph_us
+                us = graph_us(lambda: f(*args, **kw), n=a.reps, reps=3)
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.reps):
+                    f(*args, **kw)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / a.reps
             fl = flops(name, args, kw, out)
             by = nbytes(name, args, kw, out)
             desc = f"{name} " + " ".join(str(x) for x in s[1] if x is not None) + " " + " ".join(f"{k}={v}" for k, v in s[2] if v is not None and v is not False)
