@@ -97,7 +97,11 @@ __device__ __forceinline__ float crg_erf_f(float x) {
   const float r = __builtin_fmaf(-q * t, e, 1.0f);
   return __builtin_copysignf(r, x);
 }
+#ifdef CRG_ABL_GELU  // timing ablation only (tools/build_variant.sh): what the GEGLU epilogue's erf costs
+__device__ __forceinline__ float crg_gelu_erf_f(float x) { return x; }
+#else
 __device__ __forceinline__ float crg_gelu_erf_f(float x) { return 0.5f * x * (1.0f + crg_erf_f(x * 0.70710678118654752440f)); }
+#endif
 
 template <typename T>
 struct crg_vec8;  // 8 consecutive elements of T, loaded/stored as one (bf16) or two (f32) 16-byte accesses

@@ -279,9 +279,14 @@ __global__ __launch_bounds__(256 * KG) void gemm_kernel(GemmP p) {
 // CU (2 x 74 KB); grids that cannot put two blocks on a CU anyway run STAGES = 4 (147 KB) so that a lone block still
 // covers the ~1.5 us global -> LDS latency.
 
-// (launch bounds: configuration A - 128-row tiles, 4 waves, 2 stages - is built for TWO blocks per CU: its register budget is 256)
+// (launch bounds: configuration A - 128-row tiles, 4 waves, 2 stages - is built for TWO blocks per CU: its register budget is 256.  The
+// plain instantiations fit it on their own (156 VGPRs + 80 accumulators); the one that emits GroupNorm statistics needs the cap.)
 template <int WNT, typename YT, bool CONV, int STAGES, int WMT, int KG, int NS = 1, bool PAIR = false, bool GST = false>
-__global__ __launch_bounds__(256 * KG, (KG == 1 && WMT == 4 && STAGES == 2 && NS == 1) ? 2 : 1) void gemm_glds_kernel(GemmP p) {
+#ifndef CRG_LB_A  // dev knob (tools/build_variant.sh): 1 (default) = every configuration-A instantiation is capped at 256 registers (unified file: 191-204
+           // VGPRs, no accumulator registers; bench A/B in one call: 246.6 -> 245.6 ms), 0 = only the statistics one
+#define CRG_LB_A 1
+#endif
+__global__ __launch_bounds__(256 * KG, ((GST || CRG_LB_A) && KG == 1 && WMT == 4 && STAGES == 2 && NS == 1) ? 2 : 1) void gemm_glds_kernel(GemmP p) {
   static_assert(!PAIR || (sizeof(YT) == 2 && NS == 1), "paired columns: bf16 output, single-plane operands");
   static_assert(!GST || PAIR, "GroupNorm statistics come from the paired epilogue");  // GST: the instantiation that emits them (p.gstat set)
   // NS = 2: split-bf16 (fp32-class) operands - the activations arrive pre-split as two bf16 planes (hi = bf16(x),
@@ -1169,10 +1174,12 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   int cfg = 1;
   if (GLDS && p.splits == 1) {
     const long blocks = (long)p.tiles_m * p.tiles_n * batch;
-    static const int d_max = getenv("CRG_GEMM_D_MAX") ? atoi(getenv("CRG_GEMM_D_MAX")) : 1024;     // dev knob: 64-row tiles below this many 128-row tiles (plain epilogues)
+    static const int d_max = getenv("CRG_GEMM_D_MAX") ? atoi(getenv("CRG_GEMM_D_MAX")) : 384;      // dev knob: 64-row tiles below this many 128-row tiles (plain epilogues)
     static const int d_max_g = getenv("CRG_GEMM_D_MAXG") ? atoi(getenv("CRG_GEMM_D_MAXG")) : 384;  // ... GEGLU epilogues
+    static const int d_max_c1 = getenv("CRG_CONV1_D_MAX") ? atoi(getenv("CRG_CONV1_D_MAX")) : 384;   // ... 1x1 convs (virtual-concat skip convs)
+    // (3x3 convs keep 384: above it they run on the row-halo / ring kernels)
     if (blocks < 192) cfg = 3;
-    else if (blocks < (((CONV && p.ks != 1) || p.epi == CRG_EPI_GEGLU) ? d_max_g : d_max)) cfg = 4;  // 3x3 convs keep 384: above it they run on the row-halo / ring kernels
+    else if (blocks < (CONV ? (p.ks == 1 ? d_max_c1 : d_max_g) : (p.epi == CRG_EPI_GEGLU ? d_max_g : d_max))) cfg = 4;
   }
   if (GLDS && force) cfg = force;
   if (cfg == 3 || cfg == 4) {

@@ -128,9 +128,8 @@ class TensorKeyedCache:
         TensorKeyedCache.generation += 1
 
 
-_ROWRES = __import__("os").environ.get("CRG_ROWRES", "1") != "0"  # dev knob: 0 = never route plain K = 320 GEMMs to the row-resident kernel.
-# Round 3, device time inside a captured graph (tools/lin_probe.py), 32768 x 320 x 320: WITHOUT a residual (proj_in) 16.7 us row-resident vs
-# 19.3 us on crg_gemm's 64-row tiles; WITH a residual 22.0 vs 22.4 (equal) - so only the residual-free ones are routed.
+_ROWRES = __import__("os").environ.get("CRG_ROWRES", "0") != "0"  # dev knob: 1 = route residual-free K = 320 GEMMs with >= 16384 rows to the row-resident kernel
+# (round 3, device time inside a captured graph, tools/lin_probe.py, 32768 x 320 x 320: 16.4 us row-resident vs 15.7 us on crg_gemm - off)
 _pack_cache = TensorKeyedCache()
 _f32_cache = TensorKeyedCache()
 
