@@ -47,9 +47,17 @@ def main():
                          "auto-face-fix second pass: img2img strength 0.3 on a crop brought to 1024x1024 = UNet re-entry + VAE encode + decode)")
     ap.add_argument("--no-graph", action="store_true", help="launch the UNet eagerly instead of replaying a captured hipGraph "
                                                             "(measured A/B on MI355X: replay is 0-3 % faster and steadier)")
+    ap.add_argument("--half", default="bf16", choices=["bf16", "f16"],
+                    help="16-bit operand type of the UNet kernels: bf16 = the headline configuration (BASELINE.json configs[1]); f16 = the "
+                         "fp16-operand build of the same kernels (libcrg_hip_f16.so, the reference's own GPU dtype) - an extra, separately labelled line")
+    ap.add_argument("--unet-fp32", action="store_true",
+                    help="extra line: the fp32-class UNet (fp32 activations, split-bf16 x3 MFMA) - the configuration whose 20-step trajectory "
+                         "stays within 1e-3 of the fp32 CPU reference end to end (tests/test_hip_models.py::test_c1_sd15_full_20_step_trajectory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
+    if a.half == "f16":
+        os.environ["CRG_HALF"] = "f16"  # read by cremage_amd._lib at import: selects libcrg_hip_f16.so and torch.float16 activations
 
     from cremage_amd import dist as D
     from cremage_amd import ops, pipeline as P
@@ -69,7 +77,8 @@ def main():
 
     # ---- model: rank 0 materialises the synthetic weights, the others receive them over RCCL ----
     t0 = time.time()
-    ldm, bcast_bytes = P.build_ldm_sharded(rank, dev, unet_dtype=torch.bfloat16, vae_dtype=torch.float32, seed=1234)
+    unet_dtype = torch.float32 if a.unet_fp32 else ops.HALF
+    ldm, bcast_bytes = P.build_ldm_sharded(rank, dev, unet_dtype=unet_dtype, vae_dtype=torch.float32, seed=1234)
     if not a.no_graph:
         ldm.model.enable_hip_graph(True)
     t_build = time.time() - t0
@@ -117,9 +126,10 @@ def main():
         "metric": "images/sec SD1.5 512x512 20-step Euler ancestral (txt2img, CFG 7.5, incl. VAE decode)",
         "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "SD1.5 txt2img 512x512, batch 4 per GPU, 20-step Euler ancestral, bf16 UNet (B=8 with CFG) + "
-                               "fp32-class (split-bf16 x3) VAE decode, synthetic name-keyed weights, synthetic conditioning",
+        "dtype": "fp32-class (split-bf16 x3)" if a.unet_fp32 else ("fp16" if a.half == "f16" else "bf16"), "data": "synthetic",
+        "config": {"workload": f"SD1.5 txt2img 512x512, batch 4 per GPU, 20-step Euler ancestral, {'fp32-class (fp32 activations, split-bf16 x3 MFMA)' if a.unet_fp32 else ('fp16' if a.half == 'f16' else 'bf16')} UNet (B=8 with CFG) + "
+                               "fp32-class (split-bf16 x3) VAE decode, synthetic name-keyed weights, synthetic conditioning"
+                               + ("" if (a.half == "bf16" and not a.unet_fp32) else "  [EXTRA line: not the headline configuration, which is the bf16 UNet]"),
                    "images_per_gpu_per_step": b, "sampler": a.sampler, "sampler_steps": a.sampler_steps, "cfg_scale": 7.5,
                    "parallelism": f"batch-sharded x{world} (weights broadcast {bcast_bytes / 1e9:.2f} GB once, images all-gathered per step)"},
         "whole_path_mfma_frac": round(value / world * flops_per_image / (PEAK_BF16_TFLOPS * 1e12), 4),

@@ -9,7 +9,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CRG_LIB: developer override used for A/B runs of two builds on the same GPU box (tools/); the default is the in-tree build
-LIB_PATH = os.path.abspath(os.environ["CRG_LIB"]) if os.environ.get("CRG_LIB") else os.path.join(_HERE, "libcrg_hip.so")
+# CRG_HALF=f16: the fp16-operand build of the same kernels (libcrg_hip_f16.so); activations / packed weights are torch.float16 then
+HALF_F16 = os.environ.get("CRG_HALF", "bf16").lower() in ("f16", "fp16", "float16", "half")
+LIB_PATH = os.path.abspath(os.environ["CRG_LIB"]) if os.environ.get("CRG_LIB") else os.path.join(_HERE, "libcrg_hip_f16.so" if HALF_F16 else "libcrg_hip.so")
 
 BF16, F32, F16 = 0, 1, 2
 PREC_BF16, PREC_BF16X3 = 0, 1
@@ -81,6 +83,7 @@ class Profile(C.Structure):
 # name -> (restype, argtypes); every symbol include/crg_hip.h declares
 SIGNATURES = {
     "crg_version": (c_int, []),
+    "crg_half_kind": (c_int, []),
     "crg_ctx_create": (c_int, [c_int, C.POINTER(c_void_p)]),
     "crg_ctx_destroy": (None, [c_void_p]),
     "crg_last_error": (C.c_char_p, [c_void_p]),
@@ -141,6 +144,8 @@ def load():
         fn.argtypes = args
     if lib.crg_version() != 101:
         raise CrgError(f"libcrg_hip.so version {lib.crg_version()} does not match the binding (101)")
+    if lib.crg_half_kind() != (1 if HALF_F16 else 0):
+        raise CrgError(f"{LIB_PATH} computes in {'fp16' if lib.crg_half_kind() else 'bf16'} but CRG_HALF asks for {'fp16' if HALF_F16 else 'bf16'}")
     _lib = lib
     return lib
 

@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libcrg_hip.so")
+LIB_F16 = os.path.join(HERE, "libcrg_hip_f16.so")  # the same sources with -DCRG_F16_BUILD: fp16 operands (crg_common.h)
 SOURCES = ["crg_api.hip", "gemm_conv.hip", "conv_ring.hip", "lngemm.hip", "norms.hip", "attention.hip", "small_ops.hip"]
 HEADERS = [os.path.join(CSRC, "crg_common.h"), os.path.join(CSRC, "gemm_shared.h"), os.path.join(HERE, "..", "include", "crg_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
@@ -32,12 +33,13 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def _compile(src):
+def _compile(job):
+    src, f16 = job
     s = os.path.join(CSRC, src)
-    o = os.path.join(OBJ, src.replace(".hip", ".o"))
+    o = os.path.join(OBJ, src.replace(".hip", "_f16.o" if f16 else ".o"))
     if not (_newer(s, o) or any(_newer(h, o) for h in HEADERS)):
         return o, False
-    cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
+    cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-DCRG_F16_BUILD"] if f16 else []) + ["-c", s, "-o", o]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
@@ -49,16 +51,17 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if force:
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))
-    with cf.ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
-        res = list(ex.map(_compile, SOURCES))
-    objs = [o for o, _ in res]
-    if any(ch for _, ch in res) or not os.path.exists(LIB):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
-        if verbose:
-            print(f"[cremage_amd.build] linked {LIB}", file=sys.stderr)
+    jobs = [(s, False) for s in SOURCES] + [(s, True) for s in SOURCES]
+    with cf.ThreadPoolExecutor(max_workers=7) as ex:
+        res = list(ex.map(_compile, jobs))
+    for lib, part in ((LIB, res[:len(SOURCES)]), (LIB_F16, res[len(SOURCES):])):
+        if any(ch for _, ch in part) or not os.path.exists(lib):
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [o for o, _ in part]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+            if verbose:
+                print(f"[cremage_amd.build] linked {lib}", file=sys.stderr)
     return LIB
 
 

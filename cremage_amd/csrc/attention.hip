@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kb * 32 + r) * KROW + (2 * s + hh) * 16);
-        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kb], 0, 0, 0);
+        st[kb] = CRG_MFMA_32x32x16(kf, qf[s], st[kb]);
       }
     }
     LAP(1);
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_k
             const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + (keyoff + 8) * 2);
             vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           }
-          oacc[dv] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], oacc[dv], 0, 0, 0);
+          oacc[dv] = CRG_MFMA_32x32x16(vf, pf[kb][s2], oacc[dv]);
         }
     }
     LAP(3);
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_c
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kb * 32 + r) * KROW + (2 * s + hh) * 16);
-          st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kb], 0, 0, 0);
+          st[kb] = CRG_MFMA_32x32x16(kf, qf[s], st[kb]);
         }
       }
       if ((tile + 1 == ntiles) && (p.Nk & 63)) {
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : (KS <= 6 ? 2 : 1))) void attn_c
               const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + (keyoff + 8) * 2);
               vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
-            oacc[dv] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], oacc[dv], 0, 0, 0);
+            oacc[dv] = CRG_MFMA_32x32x16(vf, pf[kb][s2], oacc[dv]);
           }
       }
     }
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_dma_kernel(AttnP p, unsigne
           const int base = ((KC & 1) && s == KS - 1) ? kaddr_last : kaddr;
           const int lo = ((2 * s) & (SPAN - 1)) << 4, hi = ((2 * s) & ~(SPAN - 1)) << 4;
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + ((base ^ lo) + hi + kb * 32 * KC * 16));
-          st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kb], 0, 0, 0);
+          st[kb] = CRG_MFMA_32x32x16(kf, qf[s], st[kb]);
         }
       }
       LAP(1);
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_dma_kernel(AttnP p, unsigne
 #pragma unroll
         for (int e = 0; e < 16; ++e) dz[e] = 0.f;
 #pragma unroll
-        for (int i = 0; i < CRG_ATTN_DUMMY_MFMA; ++i) dz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[0], pf[0][0], dz, 0, 0, 0);
+        for (int i = 0; i < CRG_ATTN_DUMMY_MFMA; ++i) dz = CRG_MFMA_32x32x16(qf[0], pf[0][0], dz);
         asm volatile("" ::"v"(dz));
       }
 #endif
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_dma_kernel(AttnP p, unsigne
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Ks + (va ^ ((kb * 4 + 2 * s2) << 4)));
-            oacc[dv] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], oacc[dv], 0, 0, 0);
+            oacc[dv] = CRG_MFMA_32x32x16(vf, pf[kb][s2], oacc[dv]);
           }
       }
       LAP(3);
@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_sp_kernel(AttnP p, unsigned
         const char* ka = Ks + ((base ^ lo) + hi + kb * 32 * KC * 16);
         if (QPAD && s == KS - 1) ka = hh ? smem + ones_addr : ka;
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ka);
-        dst[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], dst[kb], 0, 0, 0);
+        dst[kb] = CRG_MFMA_32x32x16(kf, qf[s], dst[kb]);
       }
     }
   };
@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_sp_kernel(AttnP p, unsigned
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (va ^ ((kb * 4 + 2 * s2) << 4)));
-          oacc[dv] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pp[kb][s2], oacc[dv], 0, 0, 0);
+          oacc[dv] = CRG_MFMA_32x32x16(vf, pp[kb][s2], oacc[dv]);
         }
     }
   };
@@ -1191,14 +1191,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_sp_kernel(AttnP p, unsigned
     for (int g = 0; g < G; ++g) {
       if (g + D < G) fetch(g + D);
       if (PV && g < NPV) {
-        oacc[g >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g], pf[1 - C][(g >> 1) & 1][g & 1], oacc[g >> 2], 0, 0, 0);
+        oacc[g >> 2] = CRG_MFMA_32x32x16(fr[g], pf[1 - C][(g >> 1) & 1][g & 1], oacc[g >> 2]);
       } else {
         const int i = g - NPV, kb = i / KS, s = i - kb * KS;
         if (s == 0) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) st[1 - C][kb][e] = 0.f;
         }
-        st[1 - C][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g], qf[s], st[1 - C][kb], 0, 0, 0);
+        st[1 - C][kb] = CRG_MFMA_32x32x16(fr[g], qf[s], st[1 - C][kb]);
       }
 #pragma unroll
       for (int it = g * ITEMS / G; it < (g + 1) * ITEMS / G; ++it) item(it);

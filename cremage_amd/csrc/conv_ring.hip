@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ring_kernel(GemmP p) {
 #pragma unroll
     for (int i = 0; i < WNT; ++i)
 #pragma unroll
-      for (int j = 0; j < WMT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < WMT; ++j) acc[i][j] = CRG_MFMA_16x16x32(wf[i], xf[j], acc[i][j]);
 #endif
   };
 
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void conv3_ring_kernel(GemmP p) {
     for (int j = 0; j < WMT; ++j) asm volatile("" ::"v"(xf[j]));
 #else
 #pragma unroll
-    for (int j = 0; j < WMT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    for (int j = 0; j < WMT; ++j) acc[i][j] = CRG_MFMA_16x16x32(wf[i], xf[j], acc[i][j]);
 #endif
   };
   bf16x8 xf0[WMT], wf0[WNT], xf1[WMT], wf1[WNT];

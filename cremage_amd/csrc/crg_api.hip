@@ -44,6 +44,7 @@ crg_prof_scope::~crg_prof_scope() {
 }
 
 extern "C" int crg_version(void) { return CRG_VERSION; }
+extern "C" int crg_half_kind(void) { return CRG_HALF_KIND; }
 
 extern "C" int crg_ctx_create(int device, crg_ctx** out) {
   if (!out) return -22;

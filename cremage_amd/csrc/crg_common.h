@@ -9,10 +9,25 @@
 
 #include "../../include/crg_hip.h"
 
+// The library's 16-bit element type.  Default build: bfloat16 (BASELINE.json configs[1] says bf16).  -DCRG_F16_BUILD compiles the SAME
+// kernels for IEEE fp16 operands (libcrg_hip_f16.so): the matrix instructions are the _f16 forms - same cycles as the _bf16 ones
+// (MI355X_MICROARCH.md, Matrix cores) - every conversion / rounding is the type's own, accumulation stays fp32.  That is the arithmetic
+// of the reference's own GPU flow (fp16 weights under torch.autocast, modules/sd/image_generator.py:489-493,748-751): three more
+// mantissa bits per operand than bf16, at the price of fp16's range.  The identifier stays `bf16` in the sources: "the half type".
+#ifdef CRG_F16_BUILD
+typedef _Float16 bf16;
+#define CRG_HALF_KIND 1
+#define CRG_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define CRG_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#else
 typedef __bf16 bf16;
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define CRG_HALF_KIND 0
+#define CRG_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define CRG_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));

@@ -233,10 +233,10 @@ __global__ __launch_bounds__(256 * KG) void gemm_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (NSPLIT == 2) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xf[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = CRG_MFMA_16x16x32(wl[i], xf[j], acc[i][j]);
+            acc[i][j] = CRG_MFMA_16x16x32(wf[i], xl[j], acc[i][j]);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = CRG_MFMA_16x16x32(wf[i], xf[j], acc[i][j]);
         }
     }
     if (more) store_tile((kt + 1) & 1);
@@ -555,10 +555,10 @@ __global__ __launch_bounds__(256 * KG, ((GST || CRG_LB_A) && KG == 1 && WMT == 4
 #pragma unroll
         for (int j = 0; j < WMT; ++j) {
           if constexpr (NS == 2) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xf[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = CRG_MFMA_16x16x32(wl[i], xf[j], acc[i][j]);
+            acc[i][j] = CRG_MFMA_16x16x32(wf[i], xl[j], acc[i][j]);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = CRG_MFMA_16x16x32(wf[i], xf[j], acc[i][j]);
         }
     }
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
@@ -859,10 +859,10 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
 #pragma unroll
           for (int j = 0; j < WMT; ++j) {
             if constexpr (NS == 2) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xf[j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xl[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = CRG_MFMA_16x16x32(wl[i], xf[j], acc[i][j]);
+              acc[i][j] = CRG_MFMA_16x16x32(wf[i], xl[j], acc[i][j]);
             }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = CRG_MFMA_16x16x32(wf[i], xf[j], acc[i][j]);
           }
       }
       wbuf ^= 1;

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
 #pragma unroll
     for (int i = 0; i < WNT; ++i)
 #pragma unroll
-      for (int j = 0; j < WMT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < WMT; ++j) acc[i][j] = CRG_MFMA_16x16x32(wf[i], xf[j], acc[i][j]);
   };
   if constexpr (ALIAS) {
     // rows landed (no LayerNorm: nobody waited yet), normalised rows published -> fragments into registers -> the rows' LDS becomes

@@ -15,7 +15,7 @@ from .. import ops
 
 def compute_dtype_of(x: torch.Tensor) -> torch.dtype:
     """Activation dtype policy: bf16 stays bf16 (1-pass MFMA); everything else runs the fp32-class path."""
-    return torch.bfloat16 if x.dtype == torch.bfloat16 else torch.float32
+    return ops.HALF if x.dtype == ops.HALF else torch.float32
 
 
 class GroupNorm32(nn.GroupNorm):

@@ -175,7 +175,7 @@ class CrossAttention(nn.Module):
     def _fused(self, dtype: torch.dtype) -> bool:
         """bf16 with a head dim the flash kernel takes: projections that share an input are ONE GEMM over row-stacked weights
         and V stays row-major (ops.attention_rows_v); otherwise (fp32-class) the separate / transposed-V projections."""
-        return dtype == torch.bfloat16 and (self.to_q.weight.shape[0] // self.heads) <= 160
+        return dtype == ops.HALF and (self.to_q.weight.shape[0] // self.heads) <= 160
 
     @staticmethod
     def _stack(*ws):

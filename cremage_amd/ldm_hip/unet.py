@@ -296,7 +296,7 @@ class UNetModel(nn.Module):
             return self.compute_dtype
         p = self.time_embed[0].weight.dtype
         if p in (torch.bfloat16, torch.float16) or torch.is_autocast_enabled():
-            return torch.bfloat16
+            return ops.HALF  # the library's half type: bfloat16, or fp16 under CRG_HALF=f16
         return torch.float32
 
     def _prologue(self, timesteps, context):
@@ -320,7 +320,7 @@ class UNetModel(nn.Module):
         """out = conv3x3(SiLU(GN32(h))) (openaimodel.py:752-756,816), back to NCHW in x.dtype (:810)."""
         h = self.out[0](h, silu=True)
         h = self.out[2](h)
-        return ops.nhwc_to_nchw(h, x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32).to(x.dtype)
+        return ops.nhwc_to_nchw(h, x.dtype if x.dtype in (torch.float32, ops.HALF) else torch.float32).to(x.dtype)
 
     def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
         """x [N, C, H, W] (any float dtype, NCHW) , timesteps [N] (may be fractional), context [N, T, D]

@@ -293,7 +293,7 @@ class AutoencoderKL(nn.Module):
     def resolve_compute_dtype(self) -> torch.dtype:
         if self.compute_dtype is not None:
             return self.compute_dtype
-        return torch.bfloat16 if self.post_quant_conv.weight.dtype in (torch.bfloat16, torch.float16) else torch.float32
+        return ops.HALF if self.post_quant_conv.weight.dtype in (torch.bfloat16, torch.float16) else torch.float32
 
     def encode(self, x):
         """image [b,3,H,W] NCHW in [-1,1] -> posterior over [b,4,H/8,W/8] (autoencoder.py:324-331)."""

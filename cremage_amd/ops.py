@@ -24,7 +24,12 @@ import torch
 
 from . import _lib as L
 
-_DT = {torch.bfloat16: L.BF16, torch.float32: L.F32, torch.float16: L.F16}
+# The library's 16-bit type: bfloat16 (default) or, with CRG_HALF=f16, IEEE fp16 (the fp16-operand build of the same kernels).
+# Code L.BF16 in a dtype argument means "the library's half type" in both builds.
+HALF = torch.float16 if L.HALF_F16 else torch.bfloat16
+_DT = {HALF: L.BF16, torch.float32: L.F32}
+if not L.HALF_F16:
+    _DT[torch.float16] = L.F16  # weight sources only (crg_pack_weight converts)
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -35,13 +40,13 @@ def _dt(t: torch.Tensor) -> int:
 
 
 def _act_dt(t: torch.Tensor) -> int:
-    if t.dtype not in (torch.bfloat16, torch.float32):
-        raise L.CrgError(f"activations must be bfloat16 or float32, got {t.dtype}")
+    if t.dtype not in (HALF, torch.float32):
+        raise L.CrgError(f"activations must be {HALF} or float32, got {t.dtype}")
     return _DT[t.dtype]
 
 
 def _prec(t: torch.Tensor) -> int:
-    return L.PREC_BF16 if t.dtype == torch.bfloat16 else L.PREC_BF16X3
+    return L.PREC_BF16 if t.dtype == HALF else L.PREC_BF16X3
 
 
 def _need_cuda(*ts):
@@ -151,7 +156,7 @@ GN_STATS_MIN_HW = 512  # smaller images take the single-launch GroupNorm kernel,
 def _gn_stats_buffer(rows: int, cols: int, hw: Optional[int], in_dtype, out_dtype, device) -> Optional[torch.Tensor]:
     if not GN_STATS or not hw or hw % 32 or hw < GN_STATS_MIN_HW or rows % hw or cols % 8:
         return None
-    if in_dtype != torch.bfloat16 or out_dtype != torch.bfloat16:
+    if in_dtype != HALF or out_dtype != HALF:
         return None
     return torch.empty((2, (rows + 31) // 32, cols), dtype=torch.float32, device=device)
 
@@ -178,12 +183,14 @@ def f32_vec(v: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 def packed_weight(w: torch.Tensor, kind: int, split: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """bf16 [N, K] image of a Linear / conv weight (+ bf16 residual plane when `split`)."""
     _need_cuda(w)
-    if kind == L.PACK_LINEAR and not split and w.dtype == torch.bfloat16 and w.is_contiguous():
+    if kind == L.PACK_LINEAR and not split and w.dtype == HALF and w.is_contiguous():
         return w.detach().reshape(w.shape[0], -1), None  # zero-copy: already the packed image
     r = _pack_cache.get((w,), (kind, split))
     if r is not None:
         return r
     src = w.detach().contiguous()
+    if src.dtype not in _DT:
+        src = src.float()  # e.g. bfloat16 parameters handed to the fp16-operand build
     n_out = src.shape[0]
     if kind == L.PACK_CONV:
         n_in, ks = src.shape[1], src.shape[2]
@@ -191,7 +198,7 @@ def packed_weight(w: torch.Tensor, kind: int, split: bool) -> Tuple[torch.Tensor
     else:
         n_in, ks = src[0].numel(), 1
         cols = n_in
-    hi = torch.empty((n_out, cols), dtype=torch.bfloat16, device=w.device)
+    hi = torch.empty((n_out, cols), dtype=HALF, device=w.device)
     lo = torch.empty_like(hi) if split else None
     h = _h(w)
     L.check(L.load().crg_pack_weight(h, _st(), _p(src), _dt(src), kind, n_out, n_in, ks, _p(hi), _p(lo)), h, "crg_pack_weight")
@@ -239,7 +246,7 @@ def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """Contiguous NCHW tensor -> channels-last tensor of `dtype` (one transpose+cast kernel)."""
     _need_cuda(x)
     n, c, hh, ww = x.shape
-    if x.dtype not in (torch.float32, torch.bfloat16):
+    if x.dtype not in (torch.float32, HALF):
         x = x.float()
     x = x.contiguous()
     y = empty_image(n, c, hh, ww, dtype, x.device)
@@ -288,12 +295,12 @@ def group_norm(x: torch.Tensor, weight, bias, groups: int, eps: float, silu: boo
     if split:
         if x.dtype != torch.float32:
             raise L.CrgError("group_norm(split=True) is the fp32-class path: fp32 input expected")
-        hi, lo = empty_image(n, c, hh, ww, torch.bfloat16, x.device), empty_image(n, c, hh, ww, torch.bfloat16, x.device)
+        hi, lo = empty_image(n, c, hh, ww, HALF, x.device), empty_image(n, c, hh, ww, HALF, x.device)
         L.check(L.load().crg_groupnorm_split(h, _st(), _p(x), _p(x2), c1, _p(f32_vec(weight)), _p(f32_vec(bias)), _p(hi), _p(lo), n, hh * ww, c,
                                              groups, eps, int(silu)), h, "crg_groupnorm_split")
         return hi, lo
     y = empty_image(n, c, hh, ww, x.dtype, x.device)
-    if x.dtype == torch.bfloat16:
+    if x.dtype == HALF:
         # statistics handed over by the producer(s) of x (and x2): no statistics pass over the tensor
         st1 = _gn_stats_of(x, hh * ww)
         st2 = _gn_stats_of(x2, hh * ww) if x2 is not None else None
@@ -351,7 +358,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     out_dtype = out_dtype or x.dtype
     if split and out_dtype != torch.float32:
         raise L.CrgError("linear: fp32 (BF16X3) inputs produce fp32 outputs")
-    if _ROWRES and act is None and residual is None and gn_hw is None and out_dtype == torch.bfloat16 and M >= 16384 and ln_linear_ok(x, weight):
+    if _ROWRES and act is None and residual is None and gn_hw is None and out_dtype == HALF and M >= 16384 and ln_linear_ok(x, weight):
         # K = 320 with many rows (the 64x64 level's to_out / proj_in / proj_out): the row-resident kernel without its LayerNorm
         return ln_linear(x, None, None, 0.0, weight, bias, residual=residual)
     geglu = act == "geglu"
@@ -384,7 +391,7 @@ def ln_linear_ok(x: torch.Tensor, weight: torch.Tensor, act: Optional[str] = Non
     predicate ALONE and fall back to layer_norm + linear otherwise: bf16 tokens of width 320; N a multiple of 8 (GEGLU: of 32,
     packed value / gate groups); a transposed column range starts on a tile boundary (tile = 160 columns when N % 160 == 0, else
     128) of a [B, T, K] input without activation; x, w and y (and the V^T output) each below 2 GiB."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 320 and weight[0].numel() == 320):
+    if not (x.is_cuda and x.dtype == HALF and x.shape[-1] == 320 and weight[0].numel() == 320):
         return False
     N = weight.shape[0]
     M = x.numel() // 320
@@ -472,7 +479,7 @@ def linear_transposed(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
               epilogue=L.EPI_NONE, a_dtype=L.BF16, y_dtype=L.BF16, prec=L.PREC_BF16, a_is_weight=1, a_lo=None)
     else:
         # fp32 activations cannot sit on the pre-split W side: split them once on the fly (crg_split_bf16, no torch arithmetic)
-        xh, xl = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device), torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        xh, xl = torch.empty(x.shape, dtype=HALF, device=x.device), torch.empty(x.shape, dtype=HALF, device=x.device)
         L.check(L.load().crg_split_bf16(h, _st(), _p(x), _p(xh), _p(xl), x.numel()), h, "crg_split_bf16")
         _gemm(h, a=hi.data_ptr(), lda=K, a_bstride=0, a_lo=lo.data_ptr(), w=xh.data_ptr(), w_lo=xl.data_ptr(), ldw=K,
               w_bstride=T * K, bias=b.data_ptr() if b is not None else None,
@@ -488,7 +495,7 @@ def split_bf16(x: torch.Tensor):
     _need_cuda(x)
     x = to_channels_last(x)
     n, c, hh, ww = x.shape
-    hi, lo = empty_image(n, c, hh, ww, torch.bfloat16, x.device), empty_image(n, c, hh, ww, torch.bfloat16, x.device)
+    hi, lo = empty_image(n, c, hh, ww, HALF, x.device), empty_image(n, c, hh, ww, HALF, x.device)
     h = _h(x)
     L.check(L.load().crg_split_bf16(h, _st(), _p(x), _p(hi), _p(lo), x.numel()), h, "crg_split_bf16")
     return hi, lo
@@ -507,7 +514,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     x = to_channels_last(x)
     if x_lo is not None:
         x_lo = to_channels_last(x_lo)
-        if x.dtype != torch.bfloat16 or x_lo.dtype != torch.bfloat16 or x_lo.shape != x.shape or x2 is not None:
+        if x.dtype != HALF or x_lo.dtype != HALF or x_lo.shape != x.shape or x2 is not None:
             raise L.CrgError("conv2d: x / x_lo must be two bf16 planes of one shape (and no second input)")
     n, c1, hh, ww = x.shape
     c2 = 0
@@ -593,7 +600,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, n_
     Dh = Cc // heads
     ld = vt.shape[-1]
     h = _h(q)
-    if q.dtype == torch.bfloat16 and Dh <= 160:
+    if q.dtype == HALF and Dh <= 160:
         # q / k may be column slices of one fused projection output: rows keep their parent stride
         def rows(t):
             if t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
@@ -619,7 +626,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, n_
     def planes(t):
         if not split:
             return t, None
-        th, tl = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device), torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+        th, tl = torch.empty(t.shape, dtype=HALF, device=t.device), torch.empty(t.shape, dtype=HALF, device=t.device)
         L.check(L.load().crg_split_bf16(h, _st(), _p(t), _p(th), _p(tl), t.numel()), h, "crg_split_bf16")
         return th, tl
     kh, kl = planes(k)            # [B, Nk, C]
@@ -657,7 +664,7 @@ def attention_rows_v(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: i
     B, Nq, Cc = q.shape
     Nk = k.shape[1]
     Dh = Cc // heads
-    if q.dtype != torch.bfloat16 or Dh > 160 or k.shape != v.shape or k.shape[0] != B or k.shape[2] != Cc:
+    if q.dtype != HALF or Dh > 160 or k.shape != v.shape or k.shape[0] != B or k.shape[2] != Cc:
         raise L.CrgError("attention_rows_v: bf16 q / k / v with matching shapes and d_head <= 160 expected")
 
     def rows(t):

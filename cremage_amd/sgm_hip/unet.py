@@ -166,4 +166,4 @@ class UNetModel(nn.Module):
         for module in self.output_blocks:
             h = module((h, hs.pop()), emb, context)
         h = self.out[2](self.out[0](h, silu=True))
-        return ops.nhwc_to_nchw(h, x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32).to(x.dtype)
+        return ops.nhwc_to_nchw(h, x.dtype if x.dtype in (torch.float32, ops.HALF) else torch.float32).to(x.dtype)

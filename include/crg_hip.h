@@ -52,6 +52,11 @@ enum crg_bias_mode { CRG_BIAS_NONE = 0, CRG_BIAS_COL = 1 /* bias[n] */, CRG_BIAS
 
 /* ---- context ------------------------------------------------------------------------- */
 int crg_version(void);
+/* Which 16-bit element type this build of the library computes in: 0 = bfloat16 (libcrg_hip.so, the default and what
+ * BASELINE.json configs[1] names), 1 = IEEE fp16 (libcrg_hip_f16.so: the same kernels with the _f16 matrix instructions - the
+ * operand type of the reference's own GPU flow, image_generator.py:489-493,748-751).  In either build `CRG_BF16` in a dtype argument
+ * means "the library's half type"; the caller must hand it tensors of that type (cremage_amd.ops does: ops.HALF). */
+int crg_half_kind(void);
 int crg_ctx_create(int device, crg_ctx** out);
 void crg_ctx_destroy(crg_ctx* ctx);
 const char* crg_last_error(crg_ctx* ctx);
