@@ -1171,6 +1171,10 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   // CU after that (short K) change the tile / wave configuration.
   p.tiles_m = (p.M + 127) / 128;
   p.splits = choose_splits(p, p.tiles_n * p.tiles_m, batch);
+  if constexpr (GLDS && !CONV && sizeof(YT) == 2) {
+    // persistent 256-row tiles (gemm_ring.hip) where every CU gets at least (almost) one: more FLOP per staged byte, no per-tile prologue
+    if (ring_gemm_ok(p, batch, ctx->n_cu)) return launch_gemm_ring(ctx, st, p, wk.flops, wk.bytes);
+  }
   int cfg = 1;
   if (GLDS && p.splits == 1) {
     const long blocks = (long)p.tiles_m * p.tiles_n * batch;

@@ -74,6 +74,26 @@ def test_linear_shapes(dtype, M, N, K):
     check(got2, ref2, dtype, "linear+silu")
 
 
+def test_linear_ring_gemm():
+    """The persistent 256-row ring GEMM (gemm_ring.hip) against PyTorch in a child process that routes EVERY eligible shape to it
+    (CRG_GEMM_RING=2, CRG_GEMM_RING_MIN=50: the knobs are read once per process; the default rule only takes GEGLU GEMMs with >= 3
+    tiles per CU): several tiles per block (the ring runs across tile boundaries), ragged M (rows past M come from the descriptor's
+    range check, their stores are dropped), an N that is no multiple of the tile width, residual / bias / GEGLU epilogues, both tile
+    widths; the GEGLU call is bitwise reproducible."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import REPO
+    env = dict(os.environ, CRG_GEMM_RING="2", CRG_GEMM_RING_MIN="50")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_ring_gemm_run.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RING_GEMM_RESULT ")][-1][len("RING_GEMM_RESULT "):])
+    assert len(res) == 8
+    for k, (rel, mx, scale, same) in res.items():
+        assert rel < 6e-3 and mx < scale * 2 ** -6 + 1e-3 and same, (k, rel, mx, scale, same)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_batched_tokens_and_f32_out(dtype):
     from cremage_amd import ops
