@@ -37,7 +37,7 @@ def slot_of(name):
     if m:
         wnt, conv, ns = m.group(1), m.group(2) == "1", m.group(3)
     else:
-        m = re.search(r"gemm_glds_kernel<(\d), (bool _Accum, bool, E|[\w ]+, (?:true|false)), \d+, \d+, \d+, (\d+), (?:true|false)>", name)
+        m = re.search(r"gemm_glds_kernel<(\d), (bool _Accum, bool, E|[\w ]+, (?:true|false)), \d+, \d+, \d+, (\d+), (?:true|false)(?:, (?:true|false))?>", name)
         if m:
             wnt, ns = m.group(1), m.group(3)
             conv = m.group(2).startswith("bool _Accum") or m.group(2).endswith("true")
@@ -53,11 +53,15 @@ def slot_of(name):
     m = re.search(r"conv3_ring_kernelILi(\d)E", name) or re.search(r"conv3_ring_kernel<(\d),", name)
     if m:
         return "conv_w" + m.group(1)
+    m = re.search(r"gemm_ring_kernelILi(\d)E", name) or re.search(r"gemm_ring_kernel<(\d),", name)
+    if m:
+        return "gemm_w" + m.group(1)
     if "lngemm_kernel" in name:
         return "lngemm"
     if "gemm_kernel" in name:
         return "conv_x3" if (("Lb1E" in name) or re.search(r", true[,>]", name)) else "gemm_x3"
-    for pat, slot in (("splitk_reduce", "splitk_reduce"), ("attn_kernel", "attention"), ("attn_sp_kernel", "attention"), ("attn_dma_kernel", "attention"), ("gn_stats", "gn_stats"), ("gn_apply", "gn_apply"), ("gn_small", "gn_apply"),
+    for pat, slot in (("splitk_reduce", "splitk_reduce"), ("attn_kernel", "attention"), ("attn_sp_kernel", "attention"), ("attn_dma_kernel", "attention"), ("attn_ctx_kernel", "attention"),
+                      ("gn_stats", "gn_stats"), ("gn_finalize", "gn_stats"), ("gn_apply", "gn_apply"), ("gn_small", "gn_apply"),
                       ("layernorm_kernel", "layernorm"), ("softmax_rows", "softmax"), ("conv_small", "conv_small")):
         if pat in name:
             return slot
