@@ -41,6 +41,7 @@ class GemmArgs(C.Structure):
         ("a_is_weight", c_int),
         ("a_lo", c_void_p),
         ("gn_stats", c_void_p),
+        ("vt", c_void_p), ("vt_n0", c_int), ("vt_tokens", c_int), ("vt_ld", c_int64),
     ]
 
 

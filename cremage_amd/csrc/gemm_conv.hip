@@ -582,6 +582,45 @@ __global__ __launch_bounds__(256 * KG, ((GST || CRG_LB_A) && KG == 1 && WMT == 4
 #pragma unroll
       for (int j = 0; j < WMT; ++j) acc[i][j] += red[(i * WMT + j) * 64];
   }
+  if constexpr (PAIR && !CONV && !GST) {
+    if (p.vt && n0 >= p.vt_n0) {
+      // transposed n-tile (the V third of a fused Q | K | V projection -> V^T [sample][channel][token], what the LDS-DMA / pipelined
+      // attention kernels stage): lane = one token x 8 (4) consecutive channels -> one 2-byte store per channel; the 16 lanes of a
+      // DPP row hold 16 consecutive tokens, i.e. 32 contiguous bytes of a V^T row per store instruction and row
+      const int Cv = p.N - p.vt_n0;
+      const int nb = n0 + wn * (16 * WNT);
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) {
+        const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
+        if (m >= p.M) continue;
+        const int bs = m / p.vt_T, tk = m - bs * p.vt_T;
+        bf16* V = p.vt + ((long)bs * Cv - p.vt_n0) * p.vt_ld + tk;
+#pragma unroll
+        for (int u = 0; u < WNT / 2; ++u) {
+          const int n = nb + 32 * u + 8 * fq;
+          if (n >= p.N) continue;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float v = e < 4 ? acc[2 * u][j][e] : acc[2 * u + 1][j][e - 4];
+            if (pre_bias) v += e < 4 ? bpre[2 * u][e] : bpre[2 * u + 1][e - 4];
+            V[(long)(n + e) * p.vt_ld] = (bf16)v;
+          }
+        }
+        if constexpr (WNT & 1) {
+          const int n = nb + 16 * (WNT - 1) + 4 * fq;
+          if (n < p.N) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v = acc[WNT - 1][j][e];
+              if (pre_bias) v += bpre[WNT - 1][e];
+              V[(long)(n + e) * p.vt_ld] = (bf16)v;
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
   if constexpr (PAIR) {
     gemm_epilogue_pairs<WNT, WMT, GST ? 1 : 0>(p, acc, m0, n0, wm, wn, frow, fq, bz, r2, r1, pre_res, bpre, pre_bias);
   } else {
@@ -1103,6 +1142,8 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
             (p.y_bs & 7) == 0 && ((uintptr_t)p.y & 15) == 0 &&
             (!p.res || ((p.ldr & 7) == 0 && (p.r_bs & 7) == 0 && ((uintptr_t)p.res & 15) == 0)) &&
             (!p.cvec || (p.cvec_ld & 3) == 0)) ? 1 : 0;
+  if (p.vt && !(p.pair && p.splits == 1 && !p.gstat && !CONV))
+    return crg_fail(ctx, -22, "gemm: a transposed column range needs the paired bf16 epilogue of an unsplit, unbatched GEMM (N, ldy multiples of 8, K below the split-K rule)");
   if (p.gstat && !p.pair && (p.splits == 1 || p.inred))
     return crg_fail(ctx, -22, "gemm/conv: GroupNorm statistics come from the paired bf16 epilogue (N, ldy, ldr multiples of 8, 16-byte aligned y / residual, no GEGLU)");
   void (*kern)(GemmP);
@@ -1383,6 +1424,16 @@ extern "C" int crg_gemm(crg_ctx* ctx, void* stream, const crg_gemm_args* a) {
   p.cvec = nullptr; p.cvec_rows = 1; p.cvec_ld = 0; p.a_is_weight = a->a_is_weight;
   p.gstat = a->gn_stats; p.gstat_plane = (long)((a->M + 31) / 32) * a->N;
   if (a->gn_stats) CRG_REQUIRE(ctx, ((uintptr_t)a->gn_stats & 15) == 0, "gemm: gn_stats must be 16-byte aligned");
+  if (a->vt) {
+    const int bn_ = a->N % 160 == 0 ? 160 : 128;
+    CRG_REQUIRE(ctx, a->prec == CRG_PREC_BF16 && a->a_dtype == CRG_BF16 && a->y_dtype == CRG_BF16 && a->batch == 1 && a->epilogue == CRG_EPI_NONE &&
+                         !a->residual && !a->gn_stats && (a->bias_mode == CRG_BIAS_COL || !a->bias),
+                "gemm: a transposed column range needs a plain bf16 GEMM (no batch / residual / activation / statistics)");
+    CRG_REQUIRE(ctx, a->vt_n0 > 0 && a->vt_n0 < a->N && a->vt_n0 % bn_ == 0 && a->N > 32 && a->vt_tokens > 0 && a->M % a->vt_tokens == 0 && a->vt_ld >= a->vt_tokens &&
+                         ((uintptr_t)a->vt & 1) == 0,
+                "gemm: transposed range n0=%d (tile %d) tokens=%d ld=%ld inconsistent with M=%d N=%d", a->vt_n0, bn_, a->vt_tokens, (long)a->vt_ld, a->M, a->N);
+    p.vt = (bf16*)a->vt; p.vt_n0 = a->vt_n0; p.vt_T = a->vt_tokens; p.vt_ld = a->vt_ld;
+  }
   const double flops = 2.0 * a->M * (double)a->N * a->K * a->batch;
   const double bytes = ((double)a->M * a->K * crg_dtype_size(a->a_dtype) + (double)a->N * a->K * 2 +
                         (double)a->M * a->N * crg_dtype_size(a->y_dtype) * (a->residual ? 2 : 1)) * a->batch;

@@ -362,7 +362,7 @@ bool ring_gemm_ok(const GemmP& p, int batch, int n_cu) {
   static const int min_pct = getenv("CRG_GEMM_RING_MIN") ? atoi(getenv("CRG_GEMM_RING_MIN")) : 300;  // dev knob: least tiles, % of the CU count
   if (!on || batch != 1 || p.K % 64 || p.K < 128 || p.splits != 1) return false;
   if (p.epi != CRG_EPI_GEGLU && !(on >= 2 && p.epi == CRG_EPI_NONE)) return false;
-  if (p.bias_mode == CRG_BIAS_ROW || p.cvec || p.gstat) return false;
+  if (p.bias_mode == CRG_BIAS_ROW || p.cvec || p.gstat || p.vt) return false;
   const bool geglu = p.epi == CRG_EPI_GEGLU;
   if (geglu ? (p.N % 32 || (p.ldy & 3)) : (p.N % 8 || (p.ldy & 7) || ((uintptr_t)p.y & 15))) return false;
   if (p.res && ((p.ldr & 7) || ((uintptr_t)p.res & 15))) return false;

@@ -38,6 +38,10 @@ struct GemmP {
   // the FINISHED (bf16-rounded) outputs: gstat[0][rb][n] / gstat[1][rb][n], plane stride gstat_plane floats.  Written by the paired
   // epilogue or, for split-K launches, by the reduce kernel; null = none.
   float* gstat; long gstat_plane;
+  // transposed column range (crg_gemm_args.vt): output columns n >= vt_n0 (a multiple of the tile width) go to
+  // vt[(m / vt_T) * (N - vt_n0) + n - vt_n0][m % vt_T] (row length vt_ld) instead of y: the V^T operand of crg_attention out of the
+  // same launch as Q | K (gemm_glds_kernel, paired epilogue; null = none)
+  bf16* vt; int vt_n0, vt_T; long vt_ld;
 };
 
 constexpr int BM = 128;

@@ -32,6 +32,7 @@ from .nn import Conv2d, Linear, Normalize, zero_module
 import os
 
 _SELF_QKV = os.environ.get("CRG_SELF_QKV", "1") != "0"  # dev knob: 0 = self-attention as fused Q|K GEMM + transposed-V GEMM (round-1 form)
+_SELF_VT = os.environ.get("CRG_SELF_VT", "1") != "0"    # dev knob: 0 = V stays row-major in the fused projection (round-2 form) at every level
 
 
 def exists(v):
@@ -235,6 +236,16 @@ class CrossAttention(nn.Module):
                 # 64x64 level: LayerNorm + Q | K | V in ONE launch whose V third is written transposed, so that the 4096-token
                 # self-attention runs on the transposed-V flash kernel (the row-major-V variant is 10-20 % slower there)
                 qk, vt = ops.ln_linear(x, ln.weight, ln.bias, ln.eps, wqkv, transposed_from=2 * c)
+                out = ops.attention(qk[..., :c], qk[..., c:], vt, self.heads, x.shape[1], self.scale)
+                return ops.linear(out, _eff(self, self.to_out[0].weight, "out"), self.to_out[0].bias, residual=residual)
+            if fused and _SELF_QKV and _SELF_VT and x.dim() == 3 and x.shape[1] % 64 == 0 and (c // self.heads) in (40, 64, 80) \
+                    and ops.linear_transposed_ok(x, wqkv, 2 * c):
+                # head dims with an LDS-DMA / pipelined attention kernel (they stage V^T): the V third of the fused projection comes
+                # out transposed from the GEMM's own epilogue.  Device time in a graph, 8 x 1024 tokens, d 80: attention 43.6 -> 30.2 us;
+                # SDXL 4 x 4096, d 64: 256 -> 205 us (tools/attn_vt_probe.py)
+                if ln is not None:
+                    x, ln = ops.layer_norm(x, ln.weight, ln.bias, ln.eps), None
+                qk, vt = ops.linear(x, wqkv, transposed_from=2 * c)
                 out = ops.attention(qk[..., :c], qk[..., c:], vt, self.heads, x.shape[1], self.scale)
                 return ops.linear(out, _eff(self, self.to_out[0].weight, "out"), self.to_out[0].bias, residual=residual)
             if fused and _SELF_QKV:

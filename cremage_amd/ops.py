@@ -343,10 +343,14 @@ def _gemm(h, **kw):
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-           act: Optional[str] = None, out_dtype: Optional[torch.dtype] = None, gn_hw: Optional[int] = None) -> torch.Tensor:
+           act: Optional[str] = None, out_dtype: Optional[torch.dtype] = None, gn_hw: Optional[int] = None,
+           transposed_from: Optional[int] = None):
     """y = act(x @ weight^T + bias) + residual over the last dim of x.
     weight: [N, K] (nn.Linear) or [N, K, 1, 1] (1x1 conv).  act: None | 'silu' | 'geglu'.
-    gn_hw: y (as an image of gn_hw tokens per sample) feeds a GroupNorm - emit its statistics side channel (bf16 only, see above)."""
+    gn_hw: y (as an image of gn_hw tokens per sample) feeds a GroupNorm - emit its statistics side channel (bf16 only, see above).
+    transposed_from = n0 (test linear_transposed_ok first; x must be [B, T, K]): output columns >= n0 are returned as a SECOND tensor
+    [B, N - n0, ld], ld = roundup(T, 8), transposed per sample - the V^T operand of `attention` out of the same launch as Q | K; the
+    first tensor then has n0 columns."""
     _need_cuda(x, weight, bias, residual)
     x = x.contiguous()
     K = x.shape[-1]
@@ -364,6 +368,15 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     geglu = act == "geglu"
     hi, lo = packed_weight(weight, L.PACK_GEGLU if geglu else L.PACK_LINEAR, split)
     n_out = N // 2 if geglu else N
+    vt, vt_tokens, vt_ld = None, 0, 0
+    if transposed_from is not None:
+        if not linear_transposed_ok(x, weight, transposed_from) or act is not None or residual is not None or gn_hw is not None:
+            raise L.CrgError("linear: transposed_from outside its domain (test linear_transposed_ok; no activation / residual / statistics)")
+        n_out, vt_tokens = transposed_from, x.shape[1]
+        vt_ld = (vt_tokens + 7) // 8 * 8
+        vt = torch.empty((x.shape[0], N - transposed_from, vt_ld), dtype=x.dtype, device=x.device)
+        if vt_ld != vt_tokens:
+            vt[:, :, vt_tokens:].zero_()
     y = torch.empty(x.shape[:-1] + (n_out,), dtype=out_dtype, device=x.device)
     b = None
     if bias is not None:
@@ -380,10 +393,22 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
           y=y.data_ptr(), ldy=n_out, y_bstride=0, M=M, N=N, K=K, batch=1,
           epilogue={None: L.EPI_NONE, "silu": L.EPI_SILU, "geglu": L.EPI_GEGLU}[act],
           a_dtype=_act_dt(x), y_dtype=_DT[out_dtype], prec=_prec(x), a_is_weight=0, a_lo=None,
-          gn_stats=stats.data_ptr() if stats is not None else None)
+          gn_stats=stats.data_ptr() if stats is not None else None,
+          vt=vt.data_ptr() if vt is not None else None, vt_n0=transposed_from or 0, vt_tokens=vt_tokens, vt_ld=vt_ld)
     if stats is not None:
         y._crg_gn_pending = stats  # the caller that shapes y into an image attaches it (image_of_stats)
-    return y
+    return (y, vt) if vt is not None else y
+
+
+def linear_transposed_ok(x: torch.Tensor, weight: torch.Tensor, n0: int) -> bool:
+    """Shapes `linear(..., transposed_from=n0)` takes: [B, T, K] tokens in the library's half type, N and n0 on tile boundaries of the
+    paired epilogue (tile = 160 columns when N % 160 == 0, else 128), K below crg_gemm's split-K rule (the transposed range comes out of
+    the GEMM's own epilogue, not out of a reduce pass)."""
+    if not (x.is_cuda and x.dim() == 3 and x.dtype == HALF):
+        return False
+    N, K = weight.shape[0], weight[0].numel()
+    bn = 160 if N % 160 == 0 else 128
+    return K == x.shape[-1] and K % 8 == 0 and K < 24 * 64 and N % 8 == 0 and 0 < n0 < N and n0 % bn == 0 and N > 32
 
 
 def ln_linear_ok(x: torch.Tensor, weight: torch.Tensor, act: Optional[str] = None, transposed_from: Optional[int] = None) -> bool:

@@ -176,6 +176,11 @@ typedef struct {
    * plane 0 = per 32-row block and column the sum of the rounded outputs y, plane 1 the sum of their squares (consumed by
    * crg_groupnorm_pre when y - e.g. proj_out + residual, attention.py:1049-1057 - feeds the next ResBlock's GroupNorm) */
   float* gn_stats;
+  /* optional transposed column range (plain bf16 GEMM, unbatched, K below the split-K rule): output columns n >= vt_n0 - a multiple
+   * of the tile width: 160 when N % 160 == 0, else 128 - go to vt[(m / vt_tokens) * (N - vt_n0) + (n - vt_n0)][m % vt_tokens] (bf16,
+   * row length vt_ld >= vt_tokens) instead of y, which then has vt_n0 columns: `to_q | to_k | to_v` of a self-attention
+   * (attention.py:614,629,636) as ONE launch whose V third comes out as the V^T operand of crg_attention */
+  void* vt; int vt_n0; int vt_tokens; int64_t vt_ld;
 } crg_gemm_args;
 int crg_gemm(crg_ctx* ctx, void* stream, const crg_gemm_args* args);
 

@@ -74,6 +74,25 @@ def test_linear_shapes(dtype, M, N, K):
     check(got2, ref2, dtype, "linear+silu")
 
 
+@pytest.mark.parametrize("B,T,K,C", [(8, 1024, 640, 640), (2, 256, 1280, 1280), (3, 1000, 320, 320), (4, 4096, 640, 640), (2, 64, 1280, 1280)])
+def test_linear_transposed_range(B, T, K, C):
+    """crg_gemm with a transposed column range (the V third of a fused Q | K | V projection written as V^T [B][C][roundup(T, 8)] by the
+    GEMM's own epilogue) on the three tile configurations (A / C / D), a token count that is no multiple of 8, and a K = 320 input
+    that would otherwise take the LayerNorm-fused kernel."""
+    from cremage_amd import ops
+    dev = _dev()
+    x, w = rnd(B, T, K, seed=310), rnd(3 * C, K, seed=311, scale=K ** -0.5)
+    assert ops.linear_transposed_ok(x.to(dev).to(BF), w.to(dev), 2 * C)
+    qk, vt = ops.linear(x.to(dev).to(BF), w.to(dev), transposed_from=2 * C)
+    ref = F.linear(q(x, BF), q(w, BF))
+    assert qk.shape == (B, T, 2 * C) and vt.shape == (B, C, (T + 7) // 8 * 8)
+    check(qk, ref[..., :2 * C], BF, "q | k")
+    check(vt[:, :, :T].transpose(1, 2), ref[..., 2 * C:], BF, "v transposed")
+    assert (vt[:, :, T:] == 0).all()
+    whole = ops.linear(x.to(dev).to(BF), w.to(dev))
+    assert torch.equal(whole[..., :2 * C], qk) and torch.equal(whole[..., 2 * C:], vt[:, :, :T].transpose(1, 2))
+
+
 def test_linear_ring_gemm():
     """The persistent 256-row ring GEMM (gemm_ring.hip) against PyTorch in a child process that routes EVERY eligible shape to it
     (CRG_GEMM_RING=2, CRG_GEMM_RING_MIN=50: the knobs are read once per process; the default rule only takes GEGLU GEMMs with >= 3
