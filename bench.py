@@ -46,7 +46,7 @@ def main():
                          "configs[1] with a ControlNet attached (SURVEY 8f row 1); c5 = configs[4]'s per-GPU unit (SDXL 1024x1024 txt2img, 1 image per GPU, then the "
                          "auto-face-fix second pass: img2img strength 0.3 on a crop brought to 1024x1024 = UNet re-entry + VAE encode + decode)")
     ap.add_argument("--no-graph", action="store_true", help="launch the UNet eagerly instead of replaying a captured hipGraph "
-                                                            "(measured A/B on MI355X: replay is 0-3 % faster and steadier)")
+                                                            "(measured A/B on MI355X: replay is 0-3 %% faster and steadier)")
     ap.add_argument("--half", default="bf16", choices=["bf16", "f16"],
                     help="16-bit operand type of the UNet kernels: bf16 = the headline configuration (BASELINE.json configs[1]); f16 = the "
                          "fp16-operand build of the same kernels (libcrg_hip_f16.so, the reference's own GPU dtype) - an extra, separately labelled line")

@@ -558,8 +558,11 @@ int launch_conv_ring(crg_ctx* ctx, hipStream_t st, const GemmP& p, int wnt, int 
   const bool lin = p.halo_lin != 0;
 #define CRG_RING_PICK(W, S) (p.pair ? (lin ? conv3_ring_kernel<W, true, S, true> : conv3_ring_kernel<W, true, S, false>) \
                                     : (lin ? conv3_ring_kernel<W, false, S, true> : conv3_ring_kernel<W, false, S, false>))
-  if (wnt == 5) kern = spread == 3 ? CRG_RING_PICK(5, 3) : spread == 2 ? CRG_RING_PICK(5, 2) : spread ? CRG_RING_PICK(5, 1) : CRG_RING_PICK(5, 0);
-  else if (wnt == 4) kern = spread == 3 ? CRG_RING_PICK(4, 3) : spread == 2 ? CRG_RING_PICK(4, 2) : spread ? CRG_RING_PICK(4, 1) : CRG_RING_PICK(4, 0);
+  // (the DMA-issue placements 2 and 3 measured no gain over 1 - DESIGN 6, round 2 - and are no longer instantiated; they stay in the
+  //  template for the record)
+  if (spread >= 4 && !p.inred) return launch_conv_pp(ctx, st, p, wnt, spread - 4);
+  if (wnt == 5) kern = spread ? CRG_RING_PICK(5, 1) : CRG_RING_PICK(5, 0);
+  else if (wnt == 4) kern = spread ? CRG_RING_PICK(4, 1) : CRG_RING_PICK(4, 0);
   else return crg_fail(ctx, -22, "conv ring: unsupported tile width %d", wnt);
 #undef CRG_RING_PICK
   const int BN = 32 * wnt, TP = 256;

@@ -1249,7 +1249,7 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   p.ring = p.inred = 0;
   if constexpr (GLDS && CONV && sizeof(YT) == 2 && (WNT == 4 || WNT == 5)) {
     // deep-ring kernel (conv_ring.hip) for the 256-row configuration; with 2..4 K slices it also sums them itself (last arriver)
-    static const int ring = getenv("CRG_RING") ? atoi(getenv("CRG_RING")) : 2;      // dev knob: 0 = 2-stage 256-row kernel, n = DMA issue schedule n - 1
+    static const int ring = getenv("CRG_RING") ? atoi(getenv("CRG_RING")) : 6;      // dev knob: 0 = 2-stage 256-row kernel, 1 / 2 = ring kernel (DMA issue at the top / behind the first MFMA block), 5 = 4-barrier ping-pong, 6 (default) = staggered waves (conv_pp.hip)
     static const int inred = getenv("CRG_INRED") ? atoi(getenv("CRG_INRED")) : 0;   // dev knob: most K slices summed in-kernel.  Default 0 = always the reduce kernel: measured SLOWER in-kernel (8x32x32 640->640 72.0 -> 78.7 us, 8x16x16 1280->1280 69.1 -> 76.4 us: 160 KB of fp32 per slice and tile is far past the few tens of KB where the guide says an in-launch seam pays)
     if (p.rowhalo == 2 && ring && p.a_bytes && p.w_bytes && (p.C2 == 0 || p.x2_bytes) && (long)p.M / (p.Ho * p.Wo) * p.H * p.W < (1 << 24)) {
       p.ring = ring;

@@ -376,6 +376,8 @@ __device__ __forceinline__ void wait_vmcnt() {  // s_waitcnt vmcnt(N) only (expc
 
 // conv_ring.hip: deep-ring 256-pixel-tile 3x3 conv (bf16), launched in place of conv3_rowhalo_kernel<.., MT = 2>
 int launch_conv_ring(crg_ctx* ctx, hipStream_t st, const GemmP& p, int wnt, int spread);
+// conv_pp.hip: the same tile and LDS images on the ping-pong schedule (waves 4-7 one barrier behind waves 0-3); spread == 4 / 5 above
+int launch_conv_pp(crg_ctx* ctx, hipStream_t st, const GemmP& p, int wnt, int sched);  // sched 0: 4-barrier ping-pong, 1: stagger
 // gemm_ring.hip: persistent 256-row-tile GEMM (bf16, plain / GEGLU epilogue), launched in place of gemm_glds_kernel where it applies
 bool ring_gemm_ok(const GemmP& p, int batch, int n_cu);
 int launch_gemm_ring(crg_ctx* ctx, hipStream_t st, const GemmP& p, double flops, double bytes);
