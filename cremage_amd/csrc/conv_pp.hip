@@ -70,6 +70,16 @@ __device__ __forceinline__ void pp_dma16(const void* base, unsigned bytes, char*
   } while (0)
 #define PP_SB __builtin_amdgcn_sched_barrier(0)
 
+#ifdef CRG_PP_STAMPS
+// dev instrumentation (tools/pp_stamp_probe.py; tools/build_one_variant.sh stamps conv_pp -DCRG_PP_STAMPS): wall_clock64 stamps of wave 0
+// of every block: 0 entry, 1 first DMA piece about to be issued, 2 first operands landed (prologue barrier passed), 3 K loop done, 4 epilogue
+// stores issued
+__device__ unsigned long long crg_pp_stamps[1024 * 8];
+#define PP_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) crg_pp_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define PP_STAMP(i)
+#endif
+
 }  // namespace
 
 template <int WNT, bool PAIR, bool LIN, int SCHED>
@@ -83,6 +93,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int t = threadIdx.x;
+  PP_STAMP(0);
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const bool grp_b = wave >= 4;  // the second-dispatched half: SIMD partners of waves 0-3
@@ -522,6 +533,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(GemmP p) {
     int tt = 0;
     if constexpr (!GB) {  // waves 0-3 read their first fragments behind the prologue's wait (every later set: one interval ahead)
       PP_BARRIER();
+      PP_STAMP(2);
       reads(g_begin, 0, K0{});
     }
     for (int g = g_begin; g + 1 < g_end; ++g, tt += 3) {
@@ -535,6 +547,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(GemmP p) {
   };
   if (NT > 0) {
     // prologue: X(g0), W(0), W(1), W(2); W(0), W(1) and X(g0) have to be there (waves 0-3 read k-tile 1 during interval 0)
+    PP_STAMP(1);
     {
       const XGroup xg = x_group(g_begin);
 #pragma unroll
@@ -553,12 +566,22 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(GemmP p) {
     fetch_res();
   }
   }
+  PP_STAMP(3);
   if constexpr (PAIR) {
     gemm_epilogue_pairs<WNT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, 0, r2, r1, pre_res, bpre, pre_bias);
   } else {
     gemm_epilogue<WNT, bf16, WMT>(p, acc, m0, n0, wm, wn, frow, fq, 0, sid, rres, pre_res, bpre, pre_bias);
   }
+  PP_STAMP(4);
 }
+
+#ifdef CRG_PP_STAMPS
+}  // namespace crg_mm
+extern "C" int crg_debug_read_pp(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(crg_mm::crg_pp_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+namespace crg_mm {
+#endif
 
 // Host entry (called from conv_ring.hip's launch_conv_ring when the ping-pong schedule is selected): bf16 in / bf16 out, no
 // in-launch split-K sum (p.inred launches stay on the ring kernel).

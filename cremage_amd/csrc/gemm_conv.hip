@@ -854,7 +854,40 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
     stage_x(g_begin, 2);
     stage_w(3 * g_begin, 0);
   }
+  // KG == 2: the two k-groups are the two waves of every SIMD (wave w and w + 4).  Run in lockstep they read their fragments together
+  // and multiply together, and the matrix pipe idles during the reads.  The second group therefore runs its MFMAs ONE K-TILE LATE, from
+  // fragments it keeps in registers across the barrier: per k-tile it first multiplies the previous k-tile's fragments (while its partner
+  // reads) and then reads this k-tile's (while its partner multiplies) - MI355X_MICROARCH.md "Two waves per SIMD" item 9.  No extra LDS:
+  // a slot is refilled one barrier after the group's reads of it have returned, as before.
+#ifdef CRG_X3_NOSTAGGER
+  constexpr bool STAG = false;
+#else
+  constexpr bool STAG = KG == 2 && WNT == 4;  // (the 160-wide split-plane tile has no registers left for a loop-carried fragment set)
+#endif
+  bf16x8 sxf[STAG ? WMT : 1], swf[STAG ? WNT : 1], sxl[STAG && NS == 2 ? WMT : 1], swl[STAG && NS == 2 ? WNT : 1];
+  if constexpr (STAG) {
+#pragma unroll
+    for (int j = 0; j < WMT; ++j) { sxf[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; if constexpr (NS == 2) sxl[j] = sxf[j]; }
+#pragma unroll
+    for (int i = 0; i < WNT; ++i) { swf[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; if constexpr (NS == 2) swl[i] = swf[i]; }
+  }
+  auto stag_mma = [&]() {
+    if constexpr (STAG) {
+#pragma unroll
+      for (int i = 0; i < WNT; ++i)
+#pragma unroll
+        for (int j = 0; j < WMT; ++j) {
+          if constexpr (NS == 2) {
+            acc[i][j] = CRG_MFMA_16x16x32(swl[i], sxf[j], acc[i][j]);
+            acc[i][j] = CRG_MFMA_16x16x32(swf[i], sxl[j], acc[i][j]);
+          }
+          acc[i][j] = CRG_MFMA_16x16x32(swf[i], sxf[j], acc[i][j]);
+        }
+    }
+  };
   int wbuf = 0;
+  auto k_loop = [&](auto GBc) {
+  constexpr bool GB = decltype(GBc)::value;
   for (int g = g_begin; g < g_end; ++g) {
     const char* xs = xbuf + ((g - g_begin) & 1) * (NS * xbuf_bytes);
 #pragma unroll
@@ -868,6 +901,44 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
       if (g + 1 < g_end) stage_x(g + 1, kw);
       __builtin_amdgcn_s_setprio(0);
       const char* ws = wring + wbuf * (NS * WS_BYTES);
+      if constexpr (STAG) {
+        // one fragment set for both groups; only the ORDER differs: group 0 reads, then multiplies; group 1 multiplies (the
+        // previous k-tile's fragments, zeros the first time), then reads
+        auto stag_reads = [&]() {
+#pragma unroll
+          for (int j = 0; j < WMT; ++j) {
+            const int off = lds_off(xb0[j] + kw, kg * 4 + fq);
+            sxf[j] = *reinterpret_cast<const bf16x8*>(xs + off);
+            if constexpr (NS == 2) sxl[j] = *reinterpret_cast<const bf16x8*>(xs + xbuf_bytes + off);
+          }
+          if (kw != 1 && lin) {
+#pragma unroll
+            for (int j = 0; j < WMT; ++j) {
+              if ((edge >> (kw == 0 ? j : 8 + j)) & 1u) {
+                sxf[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if constexpr (NS == 2) sxl[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < WNT; ++i) {
+            const int off = lds_off(wn * (16 * WNT) + i * 16 + frow, kg * 4 + fq);
+            swf[i] = *reinterpret_cast<const bf16x8*>(ws + off);
+            if constexpr (NS == 2) swl[i] = *reinterpret_cast<const bf16x8*>(ws + WS_BYTES + off);
+          }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (GB) {
+          stag_mma();
+          __builtin_amdgcn_sched_barrier(0);
+          stag_reads();
+          __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the reads have RETURNED before the next barrier lets the slot be refilled
+        } else {
+          stag_reads();
+          __builtin_amdgcn_sched_barrier(0);
+          stag_mma();
+        }
+      } else {
 #pragma unroll
       for (int k2 = 0; k2 < 2 / KG; ++k2) {
         const int ks = KG == 2 ? kg : k2;
@@ -904,9 +975,14 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
             acc[i][j] = CRG_MFMA_16x16x32(wf[i], xf[j], acc[i][j]);
           }
       }
+      }
       wbuf ^= 1;
     }
   }
+  if constexpr (STAG && GB) stag_mma();  // the last k-tile's fragments
+  };
+  if (STAG && kg == 1) k_loop(std::integral_constant<bool, true>{});
+  else k_loop(std::integral_constant<bool, false>{});
   if constexpr (KG == 2) {
     // fold the second k-group's partial tile into the first: [wave & 3][i][j][lane] f32x4 in the (now idle) weight ring / row buffers
     static_assert(KG == 1 || 4 * WNT * WMT * 64 * 16 <= 2 * NS * WS_BYTES + 2 * NS * 17 * 1024, "reduction buffer must fit in the block's LDS");
