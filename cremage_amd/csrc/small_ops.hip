@@ -8,75 +8,98 @@ template <typename T>
 __device__ __forceinline__ float ldf(const T* p) { return (float)*p; }
 
 // ---- conv (3x3 or 1x1), Cin <= 8 (conv_in): thread = (PX consecutive pixels of one image row, 8 output channels); weights in
-// LDS as [tap*Cin + ci][Cout] fp32; the whole input pixel (<= 8 channels) is one vector load per tap and the 8 outputs one
-// 16-byte store.  The kernel is LDS-read bound (two 16-byte weight reads per (tap, ci) against 8 FMAs per pixel): PX = 4 pixels share
-// every weight read (conv_in 4 -> 320 at 8 x 64 x 64: 65 -> see DESIGN us); widths that are not a multiple of 4 run PX = 1.
-template <typename XT, typename YT, int CI, int PX>
+// LDS as [tap*Cin + ci][Cout] fp32; the 8 outputs are one 16-byte store.  Round 3: the kernel size is a template parameter (the
+// runtime tap / ks, tap % ks and the 64-bit index divisions were more instructions than the FMAs), the weight image is filled by a
+// coalesced linear read, the PX + 2 input pixels of a kernel row are loaded once and shared by its three taps, and the FMAs are packed
+// pairs (v_pk_fma_f32): conv_in 4 -> 320 at 8 x 64 x 64 57 -> see DESIGN us.  Widths that are not a multiple of 4 run PX = 1.
+template <typename XT, typename YT, int CI, int PX, int KS>
 __global__ __launch_bounds__(256) void conv_small_cin_kernel(const XT* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, YT* __restrict__ y, int N, int H, int W,
-                                                             int Cout, int ks) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];  // [ks*ks*CI][Cout]
-  const int taps = ks * ks, pad = ks / 2;
+                                                             int Cout) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [KS*KS*CI][Cout]
+  constexpr int taps = KS * KS, pad = KS / 2;
+  // weight image: the source [Cout][CI][taps] is read LINEARLY (coalesced) and scattered into LDS
   for (int i = threadIdx.x; i < taps * CI * Cout; i += 256) {
-    const int co = i % Cout, k = i / Cout;
-    const int tap = k / CI, ci = k - tap * CI;
-    wl[i] = w[((long)co * CI + ci) * taps + tap];
+    const int co = i / (taps * CI), r = i - co * (taps * CI);
+    const int ci = r / taps, tap = r - ci * taps;
+    wl[(tap * CI + ci) * Cout + co] = w[i];
   }
   __syncthreads();
   const int cg = Cout >> 3;  // 8-channel groups
   const int WQ = W / PX;
-  const long total = (long)N * H * WQ * cg;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int g = (int)(idx % cg);
-    const long pq = idx / cg;
-    const int wo0 = (int)(pq % WQ) * PX;
-    const int ho = (int)((pq / WQ) % H);
-    const int n = (int)(pq / ((long)WQ * H));
-    float acc[PX][8];
-#pragma unroll
-    for (int px = 0; px < PX; ++px)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[px][e] = bias ? bias[g * 8 + e] : 0.f;
-    for (int tap = 0; tap < taps; ++tap) {
-      const int hi = ho + tap / ks - pad;
-      if ((unsigned)hi >= (unsigned)H) continue;
-      float xv[PX][CI];
+  const int total = N * H * WQ * cg;  // < 2^31 (checked by the host)
+  constexpr int SEG = PX + KS - 1;    // input pixels of one kernel row
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int g = idx % cg;
+    const int pq = idx / cg;
+    const int wq = pq % WQ, r2 = pq / WQ;
+    const int wo0 = wq * PX;
+    const int ho = r2 % H;
+    const int n = r2 / H;
+    f32x2 acc[PX][4];
+    {
+      f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+      if (bias) {
+        b0 = *reinterpret_cast<const f32x4*>(bias + g * 8);
+        b1 = *reinterpret_cast<const f32x4*>(bias + g * 8 + 4);
+      }
 #pragma unroll
       for (int px = 0; px < PX; ++px) {
-        const int wi = wo0 + px + tap % ks - pad;
+        acc[px][0] = f32x2{b0[0], b0[1]}; acc[px][1] = f32x2{b0[2], b0[3]};
+        acc[px][2] = f32x2{b1[0], b1[1]}; acc[px][3] = f32x2{b1[2], b1[3]};
+      }
+    }
+#pragma unroll
+    for (int kh = 0; kh < KS; ++kh) {
+      const int hi = ho + kh - pad;
+      if ((unsigned)hi >= (unsigned)H) continue;
+      float xr[SEG][CI];
+      const XT* xrow = x + ((long)n * H + hi) * W * CI;
+#pragma unroll
+      for (int sx = 0; sx < SEG; ++sx) {
+        const int wi = wo0 + sx - pad;
         const bool ok = (unsigned)wi < (unsigned)W;
-        const XT* xp = x + (((long)n * H + hi) * W + (ok ? wi : 0)) * CI;
+        const XT* xp = xrow + (ok ? wi : 0) * CI;
         if constexpr (CI == 4 && sizeof(XT) == 2) {
           const bf16x4 v = *reinterpret_cast<const bf16x4*>(xp);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) xv[px][c] = ok ? (float)v[c] : 0.f;
+          for (int c = 0; c < 4; ++c) xr[sx][c] = ok ? (float)v[c] : 0.f;
         } else if constexpr (CI == 4 && sizeof(XT) == 4) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(xp);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) xv[px][c] = ok ? v[c] : 0.f;
+          for (int c = 0; c < 4; ++c) xr[sx][c] = ok ? v[c] : 0.f;
         } else {
 #pragma unroll
-          for (int c = 0; c < CI; ++c) xv[px][c] = ok ? (float)xp[c] : 0.f;
+          for (int c = 0; c < CI; ++c) xr[sx][c] = ok ? (float)xp[c] : 0.f;
         }
       }
 #pragma unroll
-      for (int ci = 0; ci < CI; ++ci) {
-        const float* wp = wl + (tap * CI + ci) * Cout + g * 8;
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+      for (int kw = 0; kw < KS; ++kw) {
 #pragma unroll
-        for (int px = 0; px < PX; ++px)
+        for (int ci = 0; ci < CI; ++ci) {
+          const float* wp = wl + ((kh * KS + kw) * CI + ci) * Cout + g * 8;
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+          const f32x2 wa = {w0[0], w0[1]}, wb = {w0[2], w0[3]}, wc = {w1[0], w1[1]}, wd = {w1[2], w1[3]};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            acc[px][e] += xv[px][ci] * w0[e];
-            acc[px][4 + e] += xv[px][ci] * w1[e];
+          for (int px = 0; px < PX; ++px) {
+            const float xv = xr[px + kw][ci];
+            const f32x2 xx = {xv, xv};
+            acc[px][0] = __builtin_elementwise_fma(xx, wa, acc[px][0]);
+            acc[px][1] = __builtin_elementwise_fma(xx, wb, acc[px][1]);
+            acc[px][2] = __builtin_elementwise_fma(xx, wc, acc[px][2]);
+            acc[px][3] = __builtin_elementwise_fma(xx, wd, acc[px][3]);
           }
+        }
       }
     }
 #pragma unroll
     for (int px = 0; px < PX; ++px) {
       crg_vec8<YT> o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o.set(e, acc[px][e]);
+      for (int q = 0; q < 4; ++q) {
+        o.set(2 * q, acc[px][q][0]);
+        o.set(2 * q + 1, acc[px][q][1]);
+      }
       o.store(y + (((long)n * H + ho) * W + wo0 + px) * Cout + g * 8);
     }
   }
@@ -84,34 +107,42 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const XT* __restric
 
 // ---- conv (3x3 or 1x1), Cout <= 8 (conv_out): LPP lanes share one output pixel, each lane walks every LPP-th
 // 8-channel chunk of Cin (consecutive lanes -> consecutive 16-byte chunks: coalesced rows), partial sums are
-// combined with a shuffle tree.  Weights in LDS as [tap][Cin][CO] fp32.
-template <typename XT, typename YT, int CO, int LPP>
+// combined with a shuffle tree.  Weights in LDS as [tap][Cin][CO] fp32, CO = 4 or 8 (the VAE's 3 output channels used to pay for 8),
+// compile-time kernel size, packed FMAs.
+template <typename XT, typename YT, int CO, int LPP, int KS>
 __global__ __launch_bounds__(256) void conv_small_cout_kernel(const XT* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, YT* __restrict__ y, int N, int H, int W,
-                                                              int Cin, int Cout, int ks) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];  // [ks*ks][Cin][CO]
-  const int taps = ks * ks, pad = ks / 2;
-  for (int i = threadIdx.x; i < taps * Cin * CO; i += 256) {
-    const int co = i % CO, k = i / CO;
-    const int tap = k / Cin, ci = k - tap * Cin;
-    wl[i] = co < Cout ? w[((long)co * Cin + ci) * taps + tap] : 0.f;
+                                                              int Cin, int Cout) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [KS*KS][Cin][CO]
+  constexpr int taps = KS * KS, pad = KS / 2;
+  // weight image: zero-fill, then the source [Cout][Cin][taps] read linearly and scattered (see conv_small_cin_kernel)
+  for (int i = threadIdx.x; i < taps * Cin * CO; i += 256) wl[i] = 0.f;
+  __syncthreads();
+  {
+    const int per_co = Cin * taps;
+    for (int i = threadIdx.x; i < Cout * per_co; i += 256) {
+      const int co = i / per_co, r = i - co * per_co;
+      const int ci = r / taps, tap = r - ci * taps;
+      wl[(tap * Cin + ci) * CO + co] = w[i];
+    }
   }
   __syncthreads();
-  const long total = (long)N * H * W;
+  const int total = N * H * W;  // < 2^31 (checked by the host)
   const int sub = threadIdx.x % LPP;
-  const int ppb = 256 / LPP;  // pixels per block iteration
-  for (long pix0 = (long)blockIdx.x * ppb; pix0 < total; pix0 += (long)gridDim.x * ppb) {
-    const long pix = pix0 + threadIdx.x / LPP;
+  constexpr int ppb = 256 / LPP;  // pixels per block iteration
+  for (int pix0 = blockIdx.x * ppb; pix0 < total; pix0 += gridDim.x * ppb) {
+    const int pix = pix0 + threadIdx.x / LPP;
     const bool live = pix < total;
-    const long pp = live ? pix : total - 1;
-    const int wo = (int)(pp % W);
-    const int ho = (int)((pp / W) % H);
-    const int n = (int)(pp / ((long)W * H));
-    float acc[CO];
+    const int pp = live ? pix : total - 1;
+    const int wo = pp % W, r2 = pp / W;
+    const int ho = r2 % H;
+    const int n = r2 / H;
+    f32x2 acc[CO / 2];
 #pragma unroll
-    for (int e = 0; e < CO; ++e) acc[e] = 0.f;
+    for (int e = 0; e < CO / 2; ++e) acc[e] = f32x2{0.f, 0.f};
+#pragma unroll
     for (int tap = 0; tap < taps; ++tap) {
-      const int hi = ho + tap / ks - pad, wi = wo + tap % ks - pad;
+      const int hi = ho + tap / KS - pad, wi = wo + tap % KS - pad;
       if ((unsigned)hi >= (unsigned)H || (unsigned)wi >= (unsigned)W) continue;
       const XT* xp = x + (((long)n * H + hi) * W + wi) * Cin;
       const float* wt = wl + tap * Cin * CO;
@@ -122,28 +153,33 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const XT* __restri
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float xv = v.get(j);
+            const f32x2 xx = {xv, xv};
             const float* wp = wt + (c0 + j) * CO;
 #pragma unroll
-            for (int e = 0; e < CO; ++e) acc[e] += xv * wp[e];
+            for (int e = 0; e < CO / 2; ++e) acc[e] = __builtin_elementwise_fma(xx, *reinterpret_cast<const f32x2*>(wp + 2 * e), acc[e]);
           }
         }
       } else {
         for (int ci = sub; ci < Cin; ci += LPP) {
           const float xv = ldf(xp + ci);
+          const f32x2 xx = {xv, xv};
 #pragma unroll
-          for (int e = 0; e < CO; ++e) acc[e] += xv * wt[ci * CO + e];
+          for (int e = 0; e < CO / 2; ++e) acc[e] = __builtin_elementwise_fma(xx, *reinterpret_cast<const f32x2*>(wt + ci * CO + 2 * e), acc[e]);
         }
       }
     }
 #pragma unroll
     for (int o = 1; o < LPP; o <<= 1)
 #pragma unroll
-      for (int e = 0; e < CO; ++e) acc[e] += __shfl_xor(acc[e], o);
+      for (int e = 0; e < CO / 2; ++e) {
+        acc[e][0] += __shfl_xor(acc[e][0], o);
+        acc[e][1] += __shfl_xor(acc[e][1], o);
+      }
     if (live && sub == 0) {
-      YT* yp = y + pix * Cout;
+      YT* yp = y + (long)pix * Cout;
 #pragma unroll
       for (int e = 0; e < CO; ++e)
-        if (e < Cout) yp[e] = (YT)(acc[e] + (bias ? bias[e] : 0.f));
+        if (e < Cout) yp[e] = (YT)(acc[e >> 1][e & 1] + (bias ? bias[e] : 0.f));
     }
   }
 }
@@ -245,22 +281,28 @@ extern "C" int crg_conv_small(crg_ctx* ctx, void* stream, const void* x, const f
   const double flops = 2.0 * N * H * W * (double)Cin * Cout * ks * ks;
   const double bytes = (double)N * H * W * (Cin * crg_dtype_size(x_dtype) + Cout * crg_dtype_size(y_dtype));
   crg_prof_scope ps(ctx, st, CRG_K_CONV_SMALL, flops, bytes);
+  CRG_REQUIRE(ctx, (double)N * H * W * (Cout > 8 ? Cout / 8 : 1) < 2147483648.0, "conv_small: more than 2^31 work items");
   int rc;
   if (Cout <= 8 && (Cin > 8 || Cout <= Cin)) {
-    const size_t lds = (size_t)ks * ks * Cin * 8 * sizeof(float);
+    const int CO = Cout <= 4 ? 4 : 8;
+    const size_t lds = (size_t)ks * ks * Cin * CO * sizeof(float);
     CRG_REQUIRE(ctx, lds <= 160 * 1024, "conv_small: Cin=%d too large for the LDS weight image", Cin);
     if ((Cin & 7) == 0) CRG_REQUIRE(ctx, ((uintptr_t)x & 15) == 0, "conv_small: x must be 16-byte aligned");
     rc = by_dtype2(ctx, x_dtype, y_dtype, "conv_small", [&](auto* xs, auto* ys) {
       using XT = std::remove_const_t<std::remove_pointer_t<decltype(xs)>>;
       using YT = std::remove_pointer_t<decltype(ys)>;
       const long pixels = (long)N * H * W;
-      if (Cin >= 64) {
-        auto kern = conv_small_cout_kernel<XT, YT, 8, 8>;
+      const bool wide = Cin >= 64;  // eight lanes per pixel
+      auto go = [&](auto kern) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid_resident(pixels * 8, lds)), dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cin, Cout, ks);
+        hipLaunchKernelGGL(kern, dim3(grid_resident(wide ? pixels * 8 : pixels, lds)), dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cin, Cout);
+      };
+      if (ks == 3) {
+        if (CO == 4) wide ? go(conv_small_cout_kernel<XT, YT, 4, 8, 3>) : go(conv_small_cout_kernel<XT, YT, 4, 1, 3>);
+        else wide ? go(conv_small_cout_kernel<XT, YT, 8, 8, 3>) : go(conv_small_cout_kernel<XT, YT, 8, 1, 3>);
       } else {
-        auto kern = conv_small_cout_kernel<XT, YT, 8, 1>;
-        hipLaunchKernelGGL(kern, dim3(grid_resident(pixels, lds)), dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cin, Cout, ks);
+        if (CO == 4) wide ? go(conv_small_cout_kernel<XT, YT, 4, 8, 1>) : go(conv_small_cout_kernel<XT, YT, 4, 1, 1>);
+        else wide ? go(conv_small_cout_kernel<XT, YT, 8, 8, 1>) : go(conv_small_cout_kernel<XT, YT, 8, 1, 1>);
       }
       return 0;
     });
@@ -276,11 +318,17 @@ extern "C" int crg_conv_small(crg_ctx* ctx, void* stream, const void* x, const f
       const dim3 grid(grid_resident((long)N * H * (quad ? W / 4 : W) * (Cout / 8), lds));
       auto go = [&](auto kern) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cout, ks);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const XT*)x, w, bias, (YT*)y, N, H, W, Cout);
       };
-      if (Cin == 3) quad ? go(conv_small_cin_kernel<XT, YT, 3, 4>) : go(conv_small_cin_kernel<XT, YT, 3, 1>);
-      else if (Cin == 4) quad ? go(conv_small_cin_kernel<XT, YT, 4, 4>) : go(conv_small_cin_kernel<XT, YT, 4, 1>);
-      else go(conv_small_cin_kernel<XT, YT, 8, 1>);
+      if (ks == 3) {
+        if (Cin == 3) quad ? go(conv_small_cin_kernel<XT, YT, 3, 4, 3>) : go(conv_small_cin_kernel<XT, YT, 3, 1, 3>);
+        else if (Cin == 4) quad ? go(conv_small_cin_kernel<XT, YT, 4, 4, 3>) : go(conv_small_cin_kernel<XT, YT, 4, 1, 3>);
+        else go(conv_small_cin_kernel<XT, YT, 8, 1, 3>);
+      } else {
+        if (Cin == 3) quad ? go(conv_small_cin_kernel<XT, YT, 3, 4, 1>) : go(conv_small_cin_kernel<XT, YT, 3, 1, 1>);
+        else if (Cin == 4) quad ? go(conv_small_cin_kernel<XT, YT, 4, 4, 1>) : go(conv_small_cin_kernel<XT, YT, 4, 1, 1>);
+        else go(conv_small_cin_kernel<XT, YT, 8, 1, 1>);
+      }
       return 0;
     });
   }
