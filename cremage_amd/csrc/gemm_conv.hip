@@ -279,6 +279,16 @@ __global__ __launch_bounds__(256 * KG) void gemm_kernel(GemmP p) {
 // CU (2 x 74 KB); grids that cannot put two blocks on a CU anyway run STAGES = 4 (147 KB) so that a lone block still
 // covers the ~1.5 us global -> LDS latency.
 
+// s_waitcnt vmcnt(n * LOADS) for a wave-uniform number of k-tile batches n = 0..4 that may stay in flight
+template <int LOADS>
+__device__ __forceinline__ void wait_batches(int n) {
+  if (n <= 0) wait_vmcnt<0>();
+  else if (n == 1) wait_vmcnt<(1 * LOADS < 64 ? 1 * LOADS : 0)>();
+  else if (n == 2) wait_vmcnt<(2 * LOADS < 64 ? 2 * LOADS : 0)>();
+  else if (n == 3) wait_vmcnt<(3 * LOADS < 64 ? 3 * LOADS : 0)>();
+  else wait_vmcnt<(4 * LOADS < 64 ? 4 * LOADS : 0)>();
+}
+
 // (launch bounds: configuration A - 128-row tiles, 4 waves, 2 stages - is built for TWO blocks per CU: its register budget is 256.  The
 // plain instantiations fit it on their own (156 VGPRs + 80 accumulators); the one that emits GroupNorm statistics needs the cap.)
 template <int WNT, typename YT, bool CONV, int STAGES, int WMT, int KG, int NS = 1, bool PAIR = false, bool GST = false>
@@ -518,9 +528,76 @@ __global__ __launch_bounds__(256 * KG, ((GST || CRG_LB_A) && KG == 1 && WMT == 4
     if (kt_begin + s < nk) stage(s);
 
   int buf = 0, nbuf = D;  // ring positions of tile kt and of tile kt + D
+  // PF (the one-block-per-CU in-block split-K configuration: 64-row tiles, 8 waves, 4 stages): the fragments of k-tile kt + 1 are
+  // requested at the top of k-tile kt and consumed one barrier later, so that no MFMA block waits out an LDS round trip (a k-tile
+  // is 10 MFMAs per wave here: barrier + read latency + MFMAs in series was ~1100 cycles per k-tile for 160 cycles of matrix work).
+  // Needs k-tile kt + 1 in LDS at the top of k-tile kt: the counted wait leaves one batch fewer in flight (two k-tiles of lead).
+#ifdef CRG_GEMM_NOPF
+  constexpr bool PF = false;
+#else
+  constexpr bool PF = KG == 2 && STAGES >= 4 && NS == 1;
+#endif
+  if constexpr (PF) {
+    bf16x8 xf[2][WMT], wf[2][WNT];
+    auto reads = [&](int set, int b) {
+      const char* xs = smem + b * STAGE_BYTES;
+      const char* ws = xs + XS_BYTES;
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(xs + lds_off(wm * (16 * WMT) + j * 16 + frow, kg * 4 + fq));
+        if (set == 0) xf[0][j] = v; else xf[1][j] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < WNT; ++i) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(ws + lds_off(wn * (16 * WNT) + i * 16 + frow, kg * 4 + fq));
+        if (set == 0) wf[0][i] = v; else wf[1][i] = v;
+      }
+    };
+    auto mm = [&](const bf16x8 (&x)[WMT], const bf16x8 (&w)[WNT]) {
+#pragma unroll
+      for (int i = 0; i < WNT; ++i)
+#pragma unroll
+        for (int j = 0; j < WMT; ++j) acc[i][j] = CRG_MFMA_16x16x32(w[i], x[j], acc[i][j]);
+    };
+    // top of k-tile kt (PARITY = which fragment set holds it): k-tile kt + 1 landed, barrier, issue kt + D, request kt + 1, multiply kt
+    auto ktile = [&](int kt, auto PARc) {
+      constexpr int par = decltype(PARc)::value;
+      const int after = nk - 2 - kt;  // k-tiles issued after kt + 1 (they may stay in flight: at most D - 2)
+      wait_batches<LOADS>(after < D - 2 ? after : D - 2);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_setprio(2);
+      if (kt + D < nk) stage(nbuf);
+      __builtin_amdgcn_s_setprio(0);
+      const int b1 = (buf + 1 == STAGES) ? 0 : buf + 1;
+      if (kt + 1 < nk) reads(par ^ 1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(xf[par], wf[par]);
+      __builtin_amdgcn_sched_barrier(0);
+      buf = b1;
+      nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
+    };
+    if (kt_begin < nk) {
+      // first k-tile: wait for it alone, publish, request its fragments (the only exposed read)
+      const int newer = nk - 1 - kt_begin;
+      wait_batches<LOADS>(newer < D - 1 ? newer : D - 1);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      reads(0, 0);
+    }
+    int kt = kt_begin;
+    for (; kt + 1 < nk; kt += 2) {
+      ktile(kt, std::integral_constant<int, 0>{});
+      ktile(kt + 1, std::integral_constant<int, 1>{});
+    }
+    if (kt < nk) ktile(kt, std::integral_constant<int, 0>{});
+  } else {
   for (int kt = kt_begin; kt < nk; ++kt) {
     const int newer = nk - 1 - kt;  // tiles issued after tile kt that may stay in flight (at most D - 1)
-    if (D >= 3 && newer >= 2) wait_vmcnt<(D >= 3 ? 2 : 0) * LOADS>();
+    if constexpr (D >= 4) wait_batches<LOADS>(newer < D - 1 ? newer : D - 1);
+    else if (D >= 3 && newer >= 2) wait_vmcnt<(D >= 3 ? 2 : 0) * LOADS>();
     else if (D >= 2 && newer >= 1) wait_vmcnt<(D >= 2 ? 1 : 0) * LOADS>();
     else wait_vmcnt<0>();
     asm volatile("" ::: "memory");
@@ -563,6 +640,7 @@ __global__ __launch_bounds__(256 * KG, ((GST || CRG_LB_A) && KG == 1 && WMT == 4
     }
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
     nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
+  }
   }
   if constexpr (KG == 2) {
     // fold the second k-group's partial tile into the first: [wave&3][i][j][lane] f32x4 in the (now idle) ring
@@ -1376,7 +1454,10 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
         return launch_reduce<YT>(ctx, st, p, 1);
       }
     }
-    if (cfg == 3) rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 4, 2, 2>(ctx, st, p, batch, wk);
+#ifndef CRG_C_STAGES  // dev knob (tools/build_one_variant.sh): ring depth of configuration C
+#define CRG_C_STAGES 4
+#endif
+    if (cfg == 3) rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, CRG_C_STAGES, 2, 2>(ctx, st, p, batch, wk);
     else if (cfg == 4) rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 2, 2, 1>(ctx, st, p, batch, wk);
     else rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 2, 4, 1>(ctx, st, p, batch, wk);
   } else {
