@@ -92,7 +92,7 @@ extern "C" const char* crg_kernel_name(int slot) {
       "gemm_glds_kernel<1, YT, false, STAGES, WMT, KG>", "gemm_glds_kernel<4, YT, false, STAGES, WMT, KG>",
       "gemm_glds_kernel<5, YT, false, STAGES, WMT, KG>", "gemm_kernel<WNT, NSPLIT, AT, YT, false, KG>",
       "gemm_glds_kernel<1, YT, true, STAGES, WMT, KG>",  "conv3_ring_kernel<4, ...> | conv3_rowhalo_kernel<4, ...> | gemm_glds_kernel<4, YT, true, STAGES, WMT, KG>",
-      "conv3_ring_kernel<5, ...> | conv3_rowhalo_kernel<5, ...> | gemm_glds_kernel<5, YT, true, STAGES, WMT, KG>", "conv3_rowhalo_kernel<WNT, float, false, 2, 2> | gemm_kernel<WNT, NSPLIT, AT, YT, true, KG>",
+      "conv3_pp_kernel<5, ...> | conv3_ring_kernel<5, ...> | conv3_rowhalo_kernel<5, ...> | gemm_glds_kernel<5, YT, true, STAGES, WMT, KG>", "conv3_rowhalo_kernel<WNT, float, false, 2, 2> | gemm_kernel<WNT, NSPLIT, AT, YT, true, KG>",
       "splitk_reduce_kernel<YT>", "attn_kernel<KS, NV>", "gn_stats_kernel<T>", "gn_apply_kernel<T> / gn_small_kernel<T, VPT>", "layernorm_kernel<T>",
       "elementwise (silu / axpby / affine_cast / transpose / timestep_embedding kernels)", "conv_small_*_kernel", "softmax_rows_kernel<T>",
       "lngemm_kernel<WNT, KT, PAIR>"};

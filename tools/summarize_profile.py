@@ -53,6 +53,9 @@ def slot_of(name):
     m = re.search(r"conv3_ring_kernelILi(\d)E", name) or re.search(r"conv3_ring_kernel<(\d),", name)
     if m:
         return "conv_w" + m.group(1)
+    m = re.search(r"conv3_pp_kernelILi(\d)E", name) or re.search(r"conv3_pp_kernel<(\d),", name)
+    if m:
+        return "conv_w" + m.group(1)
     m = re.search(r"gemm_ring_kernelILi(\d)E", name) or re.search(r"gemm_ring_kernel<(\d),", name)
     if m:
         return "gemm_w" + m.group(1)
