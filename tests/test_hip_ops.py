@@ -374,6 +374,29 @@ def test_conv_ring_shapes(N, C1, C2, H, W, Co, up):
         check(got, ref, BF, f"ring conv {N}x{C1}+{C2}x{H}x{W}->{Co} up={up} {sorted(kw)}")
 
 
+def test_conv_schedules():
+    """The 256-pixel-tile 3x3 conv under every schedule the library carries, each in a child process (CRG_RING is read once per
+    process): 6 = staggered waves (conv_pp.hip, the default), 5 = its 4-barrier ping-pong form, 2 = the deep-ring kernel of round 2
+    (conv_ring.hip), 0 = the 2-stage 256-row row-halo kernel.  All of them accumulate every output in the same order (same tile,
+    same K slices, same split-K reduce), so beyond matching the fp32 reference they must agree BITWISE with each other."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import REPO
+    results = {}
+    for ring in ("6", "5", "2", "0"):
+        env = dict(os.environ, CRG_RING=ring)
+        r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_conv_sched_run.py")], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (ring, r.stderr[-3000:])
+        results[ring] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("CONV_SCHED_RESULT ")][-1][len("CONV_SCHED_RESULT "):])
+    assert len(results["6"]) == 9
+    for ring, res in results.items():
+        for case, (rel, digest) in res.items():
+            assert rel < 6e-3, (ring, case, rel)
+            assert digest == results["6"][case][1], f"CRG_RING={ring} differs from the default schedule on {case}"
+
+
 @pytest.mark.parametrize("N,C,H,W,Co", [(2, 64, 8, 8, 64), (1, 128, 16, 32, 160), (1, 64, 3, 64, 64), (1, 64, 2, 128, 64), (2, 64, 5, 12, 96)])
 def test_conv_rowhalo_upsample(N, C, H, W, Co):
     """nearest-2x upsample folded into the row-halo conv's gather (output-grid geometry, sources at (h >> 1, w >> 1)):
