@@ -73,6 +73,8 @@ class ConvArgs(C.Structure):
         ("x_dtype", c_int), ("y_dtype", c_int), ("prec", c_int),
         ("x_lo", c_void_p),
         ("gn_stats", c_void_p),
+        ("gn_gamma", c_void_p), ("gn_beta", c_void_p), ("gn_y", c_void_p),
+        ("gn_groups", c_int), ("gn_silu", c_int), ("gn_eps", C.c_float),
     ]
 
 

@@ -1202,11 +1202,150 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmP p) {
   }
 }
 
+// Split-K second pass FUSED with the GroupNorm(+SiLU) that consumes the conv's output (openaimodel.py:208 -> :229-231 inside a ResBlock),
+// for the small images of the two lowest UNet levels: one block per (sample, group) sums the K slices of its HW x gs slab in slice order,
+// adds bias / per-sample vector / residual in the order of splitk_reduce_kernel, rounds to bf16 and stores the raw output, and then
+// normalises those very values with the arithmetic of gn_small_kernel (shifted sums, wave shuffles, fixed-order cross-wave fp64
+// combine) - bitwise what the reduce kernel followed by the single-launch GroupNorm produce, in one launch and without re-reading y.
+template <int VPT>
+__global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(GemmP p) {
+  __shared__ float red[2][4];
+  __shared__ float shift_s;
+  const int n = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
+  const int C = p.N, HW = p.gn_hw;
+  const int gs = C / p.gn_groups, wv = gs >> 3;
+  const int c_beg = g * gs;
+  const int total = HW * wv;
+  const long slice = (long)p.M * p.N;
+  const float* S = p.slab;
+  bf16* Y = reinterpret_cast<bf16*>(p.y);
+  const bf16* R = reinterpret_cast<const bf16*>(p.res);
+  crg_vec8<bf16> v[VPT];
+  int row[VPT], cv[VPT];
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = t + 256 * k;
+    row[k] = i / wv;
+    cv[k] = i - row[k] * wv;
+    if (i < total) {
+      const long m = (long)n * HW + row[k];
+      const int c = c_beg + cv[k] * 8;
+      const float* sp = S + m * p.N + c;
+      f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+      for (int s2 = 1; s2 < p.splits; ++s2) {
+        a += *reinterpret_cast<const f32x4*>(sp + s2 * slice);
+        b += *reinterpret_cast<const f32x4*>(sp + s2 * slice + 4);
+      }
+      if (p.bias_mode == CRG_BIAS_COL) {
+        a += *reinterpret_cast<const f32x4*>(p.bias + c);
+        b += *reinterpret_cast<const f32x4*>(p.bias + c + 4);
+      }
+      if (p.cvec) {
+        const float* cp = p.cvec + (m / p.cvec_rows) * p.cvec_ld + c;
+        a += *reinterpret_cast<const f32x4*>(cp);
+        b += *reinterpret_cast<const f32x4*>(cp + 4);
+      }
+      if (R) {
+        const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(R + m * p.ldr + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] += (float)r8[e];
+          b[e] += (float)r8[4 + e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[k].set(e, a[e]);
+        v[k].set(4 + e, b[e]);
+      }
+      v[k].store(Y + m * p.ldy + c);
+    }
+  }
+  if (t == 0) shift_s = v[0].get(0);  // element (row 0, first channel of the group) of the rounded tensor: gn_small_kernel's shift
+  __syncthreads();
+  const float shift = shift_s;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    if (t + 256 * k < total) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[k].get(e) - shift;
+        s1 += d;
+        s2 += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  if ((t & 63) == 0) {
+    red[0][t >> 6] = s1;
+    red[1][t >> 6] = s2;
+  }
+  __syncthreads();
+  const double a = ((double)red[0][0] + (double)red[0][1]) + ((double)red[0][2] + (double)red[0][3]);
+  const double b = ((double)red[1][0] + (double)red[1][1]) + ((double)red[1][2] + (double)red[1][3]);
+  const double cnt = (double)HW * gs;
+  const double md = a / cnt;
+  double var = b / cnt - md * md;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)((double)shift + md);
+  const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+  bf16* yb = reinterpret_cast<bf16*>(p.gn_y) + (long)n * HW * C + c_beg;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    if (t + 256 * k < total) {
+      const int c = c_beg + cv[k] * 8;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gn_gamma + c), g1 = *reinterpret_cast<const f32x4*>(p.gn_gamma + c + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.gn_beta + c), b1 = *reinterpret_cast<const f32x4*>(p.gn_beta + c + 4);
+      crg_vec8<bf16> o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float ga = e < 4 ? g0[e] : g1[e - 4], be = e < 4 ? b0[e] : b1[e - 4];
+        float f = (v[k].get(e) - mean) * (rstd * ga) + be;
+        if (p.gn_silu) f = crg_silu_f(f);
+        o.set(e, f);
+      }
+      o.store(yb + (long)row[k] * C + cv[k] * 8);
+    }
+  }
+}
+
+// can the reduce behind this split-K launch also run the GroupNorm the caller asked for?
+template <typename YT>
+bool gn_slab_ok(const GemmP& p, int batch) {
+  if (sizeof(YT) != 2 || !p.gn_y || !p.gn_gamma || !p.gn_beta || batch != 1 || p.slab_row0 != 0 || p.inred || p.gstat || p.vt) return false;
+  if (p.epi != CRG_EPI_NONE || (p.bias_mode != CRG_BIAS_NONE && p.bias_mode != CRG_BIAS_COL)) return false;
+  if (p.gn_groups <= 0 || p.N % p.gn_groups || p.gn_hw <= 0 || p.M % p.gn_hw || p.ldy != p.N) return false;
+  const int gs = p.N / p.gn_groups;
+  if (gs % 8 || (p.N & 7) || (p.res && (p.ldr & 7)) || (p.cvec && (p.cvec_ld & 3))) return false;
+  return (long)p.gn_hw * (gs >> 3) <= 256 * 8;
+}
+
 // the reduce launch behind a split-K launch (whole problem, or - tail split - the rows >= slab_row0)
 template <typename YT>
 int launch_reduce(crg_ctx* ctx, hipStream_t st, const GemmP& p, int batch) {
   const long rows = p.M - p.slab_row0;
   crg_prof_scope ps(ctx, st, CRG_K_SPLITK, (double)batch * p.splits * rows * p.N, (double)batch * rows * p.N * (4.0 * p.splits + sizeof(YT)));
+  if (gn_slab_ok<YT>(p, batch)) {
+    const int vpt = (int)(((long)p.gn_hw * (p.N / p.gn_groups >> 3) + 255) / 256);
+    const dim3 grid(p.gn_groups, p.M / p.gn_hw);
+    switch (vpt) {
+      case 1: hipLaunchKernelGGL(splitk_reduce_gn_kernel<1>, grid, dim3(256), 0, st, p); break;
+      case 2: hipLaunchKernelGGL(splitk_reduce_gn_kernel<2>, grid, dim3(256), 0, st, p); break;
+      case 3: hipLaunchKernelGGL(splitk_reduce_gn_kernel<3>, grid, dim3(256), 0, st, p); break;
+      case 4: hipLaunchKernelGGL(splitk_reduce_gn_kernel<4>, grid, dim3(256), 0, st, p); break;
+      case 5: hipLaunchKernelGGL(splitk_reduce_gn_kernel<5>, grid, dim3(256), 0, st, p); break;
+      case 6: hipLaunchKernelGGL(splitk_reduce_gn_kernel<6>, grid, dim3(256), 0, st, p); break;
+      default: hipLaunchKernelGGL(splitk_reduce_gn_kernel<8>, grid, dim3(256), 0, st, p); break;
+    }
+    CRG_CHECK_LAUNCH(ctx, "splitk_reduce_gn");
+    ctx->gn_fused = true;
+    return 0;
+  }
   if (p.gstat) {
     if (batch != 1 || (p.N & 3) || (p.ldy & 3) || (p.slab_row0 & 31) || (p.res && (p.ldr & 3)))
       return crg_fail(ctx, -22, "gemm: GroupNorm statistics need an unbatched problem with 4-aligned N / ldy / ldr");
@@ -1641,9 +1780,21 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
     p.x2_bytes = xb < lim ? (unsigned)xb : 0;
     p.w_bytes = wb < lim ? (unsigned)wb : 0;
   }
+  if (a->gn_y) {
+    CRG_REQUIRE(ctx, a->gn_gamma && a->gn_beta && a->gn_groups > 0 && a->Cout % a->gn_groups == 0 && a->y,
+                "conv2d: the fused GroupNorm needs gamma, beta, a group count that divides Cout=%d and the raw output y", a->Cout);
+    CRG_REQUIRE(ctx, (((uintptr_t)a->gn_gamma | (uintptr_t)a->gn_beta | (uintptr_t)a->gn_y) & 15) == 0, "conv2d: GroupNorm pointers must be 16-byte aligned");
+    p.gn_gamma = a->gn_gamma; p.gn_beta = a->gn_beta; p.gn_eps = a->gn_eps; p.gn_groups = a->gn_groups; p.gn_silu = a->gn_silu;
+    p.gn_hw = a->Ho * a->Wo; p.gn_y = a->gn_y;
+  }
   const double flops = 2.0 * p.M * (double)p.N * p.K;
   const double bytes = (double)a->N * a->H * a->W * Ctot * crg_dtype_size(a->x_dtype) + (double)p.N * p.K * 2 +
                        (double)p.M * p.N * crg_dtype_size(a->y_dtype) * (a->residual ? 2 : 1);
-  return dispatch<true>(ctx, (hipStream_t)stream, p, 1, a->x_dtype, a->y_dtype, a->prec,
-                        Work{flops, bytes, (double)a->N * a->H * a->W * Ctot * crg_dtype_size(a->x_dtype), (double)p.N * p.K * 2});
+  ctx->gn_fused = false;
+  const int rc = dispatch<true>(ctx, (hipStream_t)stream, p, 1, a->x_dtype, a->y_dtype, a->prec,
+                                Work{flops, bytes, (double)a->N * a->H * a->W * Ctot * crg_dtype_size(a->x_dtype), (double)p.N * p.K * 2});
+  if (rc || !a->gn_y || ctx->gn_fused) return rc;
+  // not split along K (or a shape the fused kernel does not take): the GroupNorm runs as its own launch(es) on the finished y
+  return crg_groupnorm(ctx, stream, a->y, nullptr, a->Cout, a->gn_gamma, a->gn_beta, a->gn_y, a->N, a->Ho * a->Wo, a->Cout, a->gn_groups,
+                       a->gn_eps, a->gn_silu, a->y_dtype);
 }

@@ -42,6 +42,9 @@ struct GemmP {
   // vt[(m / vt_T) * (N - vt_n0) + n - vt_n0][m % vt_T] (row length vt_ld) instead of y: the V^T operand of crg_attention out of the
   // same launch as Q | K (gemm_glds_kernel, paired epilogue; null = none)
   bf16* vt; int vt_n0, vt_T; long vt_ld;
+  // GroupNorm(+SiLU) of the finished output (crg_conv_args.gn_y): when the launch is split along K and a (sample, group) slab fits one
+  // block, the kernel that sums the K slices normalises as well (splitk_reduce_gn_kernel) - no reduce launch and no second read of y
+  const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_groups, gn_silu, gn_hw; void* gn_y;
 };
 
 constexpr int BM = 128;

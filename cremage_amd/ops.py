@@ -528,8 +528,11 @@ def split_bf16(x: torch.Tensor):
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, padding=1,
            upsample2x: bool = False, x2: Optional[torch.Tensor] = None, cvec: Optional[torch.Tensor] = None,
-           residual: Optional[torch.Tensor] = None, x_lo: Optional[torch.Tensor] = None, gn_stats: bool = False) -> torch.Tensor:
+           residual: Optional[torch.Tensor] = None, x_lo: Optional[torch.Tensor] = None, gn_stats: bool = False, gn=None):
     """Implicit-GEMM conv over channels-last images.
+    `gn` = (weight, bias, groups, eps, silu): also return silu?(GroupNorm(y)) - the norm that follows the conv inside a ResBlock
+    (crg_conv_args.gn_y: on the small images of the two lowest UNet levels the launch that sums the K slices normalises as well);
+    the call then returns (y, y_norm).  bf16 outputs only; anything else raises.
     padding: int (symmetric) or (top, left, bottom, right).  `upsample2x`: nearest-2x of the input is
     folded into the gather.  `x2`: second half of a virtual channel concat.  `cvec` fp32 [N, Cout] is
     added per sample (timestep embedding); `residual` is added after.  `x_lo`: x is the bf16 hi plane of a pre-split
@@ -585,14 +588,36 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
                    cvec_ld=cvec.stride(0) if cvec is not None else 0, residual=_p(residual).value, y=y.data_ptr(), N=n, H=hh, W=ww, Cout=cout, Ho=ho, Wo=wo, ksize=ks, stride=stride,
                    pad_t=pt, pad_l=pl, upsample2x=int(upsample2x), x_dtype=_act_dt(x), y_dtype=_act_dt(y),
                    prec=L.PREC_BF16X3 if planes else _prec(x), x_lo=x_lo.data_ptr() if planes else None)
-    stats = _gn_stats_buffer(n * ho * wo, cout, ho * wo, x.dtype, y.dtype, x.device) if (gn_stats and not planes) else None
+    y_norm = keep = None
+    if gn is not None:
+        gw, gb, groups, eps, silu = gn
+        if planes or y.dtype != HALF or cout % groups or (cout // groups) % 8:
+            raise L.CrgError("conv2d: the fused GroupNorm takes bf16 outputs with 8-aligned groups")
+        y_norm = empty_image(n, cout, ho, wo, y.dtype, x.device)
+        keep = (f32_vec(gw), f32_vec(gb))
+        a.gn_gamma, a.gn_beta, a.gn_y = keep[0].data_ptr(), keep[1].data_ptr(), y_norm.data_ptr()
+        a.gn_groups, a.gn_silu, a.gn_eps = int(groups), int(bool(silu)), float(eps)
+    stats = _gn_stats_buffer(n * ho * wo, cout, ho * wo, x.dtype, y.dtype, x.device) if (gn_stats and not planes and gn is None) else None
     if stats is not None:
         a.gn_stats = stats.data_ptr()
     h = _h(x)
     L.check(L.load().crg_conv2d(h, _st(), C.byref(a)), h, "crg_conv2d")
     if stats is not None:
         y._crg_gn = (stats, y._version, ho * wo)
-    return y
+    return y if gn is None else (y, y_norm)
+
+
+def conv_gn_fusable(hw: int, dtype) -> bool:
+    """Is conv2d(..., gn=...) worth asking for?  Only where the GroupNorm would otherwise be the single-launch kernel (images below
+    GN_STATS_MIN_HW pixels, bf16): larger images take the statistics side channel + apply pair, which the fused form cannot beat."""
+    return CONV_GN and dtype == HALF and hw < GN_STATS_MIN_HW
+
+
+# dev knob: 1 = ResBlocks of the 8x8 / 16x16 levels ask for conv + GroupNorm in one call.  Default 0: measured equal-to-slower in the
+# bench (227.8 -> 228.3 ms, two alternating pairs in one gpurun call): the fused launch reads its (sample, group) slab of the fp32 K slices
+# in 160-byte row segments and takes as long as the coalesced reduce plus the single-launch GroupNorm it replaces (split-K reduce
+# +2.1 ms, GroupNorm -1.9 ms per batch); the saved launch does not pay for the access shape.
+CONV_GN = __import__("os").environ.get("CRG_CONV_GN", "0") != "0"
 
 
 def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias=None, residual: Optional[torch.Tensor] = None, gn_stats: bool = False) -> torch.Tensor:

@@ -210,6 +210,13 @@ typedef struct {
   float* gn_stats;                  /* optional GroupNorm statistics side channel of y (see crg_gemm_args.gn_stats; M = N * Ho * Wo rows,
                                        Ho * Wo % 32 == 0): the conv in front of a GroupNorm (openaimodel.py:208 -> :229-231, :234 -> the
                                        next block's :205-207) hands it the statistics, so the tensor is not read once more for them */
+  /* optional GroupNorm(+SiLU) of the finished output - the `normalization(channels)` + `SiLU` that follows the conv inside a ResBlock
+   * (openaimodel.py:208 -> :229-231; util.py:214-216): gn_y (same layout and dtype as y) = silu?(GroupNorm(y) * gn_gamma + gn_beta).
+   * y is still written.  When the conv is split along K and a (sample, group) slab of the output fits one block (the 8x8 / 16x16
+   * UNet levels) the launch that sums the K slices normalises as well; otherwise this is crg_conv2d followed by crg_groupnorm.
+   * The result is bitwise that of the two separate calls. */
+  const float* gn_gamma; const float* gn_beta; void* gn_y;
+  int gn_groups; int gn_silu; float gn_eps;
 } crg_conv_args;
 int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* args);
 

@@ -374,6 +374,41 @@ def test_conv_ring_shapes(N, C1, C2, H, W, Co, up):
         check(got, ref, BF, f"ring conv {N}x{C1}+{C2}x{H}x{W}->{Co} up={up} {sorted(kw)}")
 
 
+@pytest.mark.parametrize("N,C1,C2,H,W,Co,res", [
+    (8, 1280, 0, 16, 16, 1280, False),   # 4 K slices: the reduce launch normalises (5 vectors per thread)
+    (8, 1280, 0, 8, 8, 1280, True),      # 16 K slices, linear row buffer, residual
+    (8, 1280, 1280, 8, 8, 1280, False),  # skip concat in front
+    (2, 640, 0, 16, 16, 1280, False),    # fewer samples: other split count
+    (8, 640, 0, 32, 32, 640, False),     # 1024 pixels x 20-channel groups: gs % 8 != 0 -> raises (checked below)
+    (2, 128, 0, 16, 16, 256, False),     # not split along K: conv, then the GroupNorm as its own launch
+])
+def test_conv_gn_fused(N, C1, C2, H, W, Co, res):
+    """crg_conv_args.gn_y: conv (+bias +cvec +residual) and the GroupNorm + SiLU behind it in one call - bitwise the two separate
+    calls (the fused split-K reduce repeats their arithmetic), and the reference's values."""
+    from cremage_amd import ops
+    C = C1 + C2
+    x = rnd(N, C1, H, W, seed=280)
+    x2 = rnd(N, C2, H, W, seed=281) if C2 else None
+    w, b = rnd(Co, C, 3, 3, seed=282, scale=(9 * C) ** -0.5), rnd(Co, seed=283)
+    cvec, r = rnd(N, Co, seed=284), rnd(N, Co, H, W, seed=285)
+    g, be = (1 + 0.1 * rnd(Co, seed=286)).to(_dev()), (0.1 * rnd(Co, seed=287)).to(_dev())
+    kw = dict(x2=nhwc(x2, BF) if C2 else None, cvec=cvec.to(_dev()), residual=nhwc(r, BF) if res else None)
+    xd, wd, bd = nhwc(x, BF), w.to(_dev()), b.to(_dev())
+    if (Co // 32) % 8:
+        with pytest.raises(Exception):
+            ops.conv2d(xd, wd, bd, gn=(g, be, 32, 1e-5, True), **kw)
+        return
+    y, yn = ops.conv2d(xd, wd, bd, gn=(g, be, 32, 1e-5, True), **kw)
+    y2 = ops.conv2d(xd, wd, bd, **kw)
+    yn2 = ops.group_norm(y2, g, be, 32, 1e-5, silu=True)
+    assert torch.equal(y, y2), "raw output differs from the plain conv"
+    assert torch.equal(yn, yn2), "fused GroupNorm differs from conv -> group_norm"
+    ref = conv_ref(x, w, b, BF, x2=x2, cvec=cvec, **(dict(res=r) if res else {}))
+    check(y, ref, BF, "conv_gn raw")
+    refn = F.silu(F.group_norm(y2.float().cpu(), 32, g.cpu(), be.cpu(), 1e-5))
+    check(yn, refn, BF, "conv_gn normalised")
+
+
 def test_conv_schedules():
     """The 256-pixel-tile 3x3 conv under every schedule the library carries, each in a child process (CRG_RING is read once per
     process): 6 = staggered waves (conv_pp.hip, the default), 5 = its 4-barrier ping-pong form, 2 = the deep-ring kernel of round 2
