@@ -95,10 +95,11 @@ def main():
     def noise_sampler(sigma, sigma_next):
         return torch.stack([torch.randn((4, 64, 64), generator=g, device=dev) for g in gens])
 
-    def step():
+    def step(gather=True):
         images, _ = P.txt2img(ldm, c, uc, steps=a.sampler_steps, sampler=a.sampler, cfg_scale=7.5, height=512, width=512,
                               x0=fresh_x0(), noise_sampler=noise_sampler)
-        return D.all_gather_batch(images)
+        # gather=False: the rank-0-only profiling steps behind the timed region must not enter a collective the other ranks never join
+        return D.all_gather_batch(images) if gather else images
 
     for _ in range(a.warmup):
         step()
@@ -143,9 +144,9 @@ def main():
     # ---- roofline of the dominant kernel: HIP events on the launch stream, one extra un-timed step ----
     if rank == 0 and not a.no_roofline:
         ldm.model.enable_hip_graph(False)  # per-launch HIP events need eager launches (a replay is one opaque node list)
-        step()
+        step(gather=False)
         with ops.profile(local) as prof:
-            step()
+            step(gather=False)
         fam = prof.result
         res["roofline"] = roofline_of(prof.kernels)
         res["roofline"]["timed_eager"] = True  # this extra step is launched eagerly with an event pair around every kernel
@@ -245,10 +246,10 @@ def main_extra(a):
     if a.workload == "controlnet":
         hint = torch.stack([synth_input(f"bench.hint{first + i}", (3, hw, hw), 44, 0.5) for i in range(b)]).clamp(-1, 1).mul(0.5).add(0.5).to(dev)
 
-        def step():
+        def step(gather=True):
             images, _ = P.txt2img(ldm, c, uc, steps=a.sampler_steps, sampler=a.sampler, cfg_scale=7.5, height=hw, width=hw,
                                   x0=rnd((4, L, L)), noise_sampler=lambda s, sn: rnd((4, L, L)), hint=hint)
-            return D.all_gather_batch(images)
+            return D.all_gather_batch(images) if gather else images
         # ControlNet = encoder half + middle of the UNet + hint encoder: FLOPs counted by the profiler below, not assumed
         metric = "images/sec SD1.5 512x512 20-step Euler ancestral + ControlNet (txt2img, CFG 7.5, incl. VAE decode)"
         workload = ("SD1.5 txt2img 512x512 with a ControlNet (cldm_v15.yaml), batch 4 per GPU, 20-step Euler ancestral, bf16 UNet + "
@@ -257,10 +258,10 @@ def main_extra(a):
     else:
         img = torch.stack([synth_input(f"bench.img{first + i}", (3, hw, hw), 44, 0.5) for i in range(b)]).clamp(-1, 1).to(dev)
 
-        def step():
+        def step(gather=True):
             images, _ = P.img2img(ldm, img, c, uc, steps=a.sampler_steps, strength=0.75, cfg_scale=7.5, enc_noise=rnd((4, L, L)),
                                   fwd_noise=rnd((4, L, L)))
-            return D.all_gather_batch(images)
+            return D.all_gather_batch(images) if gather else images
         metric = "images/sec SD1.5 img2img 768x768 20-step DDIM strength 0.75 (VAE encode + 15 UNet steps x CFG + VAE decode)"
         workload = ("SD1.5 img2img 768x768 (BASELINE.json configs[3] per-GPU unit), 2 images per GPU, DDIM 20 steps, strength 0.75 -> "
                     "t_enc 15, bf16 UNet (B=4 with CFG, L=96), fp32-class VAE encode + decode, synthetic weights / inputs")
@@ -283,7 +284,7 @@ def main_extra(a):
            "model_build_s": round(t_build, 1)}
     if rank == 0 and not a.no_roofline:
         with ops.profile(local) as prof:
-            step()
+            step(gather=False)  # rank 0 only: no collective in here
         fam = prof.result
         res["roofline"] = roofline_of(prof.kernels)
         res["roofline"]["traffic"] = res["roofline"]["traffic_source"] = None  # the committed PMC passes are of the headline workload
@@ -319,7 +320,7 @@ def main_sdxl(a):
           "vector": synth_input("bench.xl.ucv", (1, 2816), 7).expand(b, -1).contiguous().to(dev)}
     gens = [torch.Generator(device=dev).manual_seed(D.image_seed(42, first + i)) for i in range(b)]
 
-    def step():
+    def step(gather=True):
         x0 = torch.stack([torch.randn((4, 128, 128), generator=g, device=dev) for g in gens])
         if c5:  # first pass, then the face-fix re-entry on a fixed 512x512 box brought to 1024x1024 (one "face" per image)
             rn = lambda: torch.stack([torch.randn((4, 128, 128), generator=g, device=dev) for g in gens])
@@ -327,7 +328,7 @@ def main_sdxl(a):
                                                   enc_noise=rn(), fwd_noise=rn())
         else:
             images, _ = P.txt2img_sdxl(eng, c, uc, steps=steps, cfg_scale=5.0, x0=x0)
-        return D.all_gather_batch(images)
+        return D.all_gather_batch(images) if gather else images
 
     for _ in range(a.warmup):
         step()
@@ -360,7 +361,7 @@ def main_sdxl(a):
            "whole_path_mfma_frac": round(value / world * flops_per_image / (PEAK_BF16_TFLOPS * 1e12), 4), "model_build_s": round(t_build, 1)}
     if rank == 0 and not a.no_roofline:
         with ops.profile(local) as prof:
-            step()
+            step(gather=False)  # rank 0 only: no collective in here
         fam = prof.result
         res["roofline"] = roofline_of(prof.kernels)
         res["roofline"]["traffic"] = res["roofline"]["traffic_source"] = None  # the committed PMC passes are of the SD1.5 workload

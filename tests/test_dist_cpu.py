@@ -154,3 +154,30 @@ def test_single_process_collectives_are_identity():
     assert D.all_gather_batch(x) is x
     assert D.broadcast_parameters_([x]) == 0
     assert D.max_over_ranks(3.5, "cpu") == 3.5
+
+
+def test_bench_rank0_only_steps_do_not_enter_collectives():
+    """bench.py runs extra, un-timed steps on rank 0 alone (per-kernel HIP events for the roofline object) after the timed region.  A
+    step() that all-gathers its images there would wait for ranks that have already left: every `step(...)` call inside an
+    `if rank == 0 ...` block must pass gather=False (it hung the multi-GPU launch otherwise - found by inspection in round 3, since no
+    multi-GPU node had run it yet)."""
+    import ast
+    import os
+    from tests.conftest import REPO
+    tree = ast.parse(open(os.path.join(REPO, "bench.py")).read())
+
+    def mentions_rank0(test):
+        return any(isinstance(n, ast.Compare) and isinstance(n.left, ast.Name) and n.left.id == "rank" and
+                   any(isinstance(c, ast.Constant) and c.value == 0 for c in n.comparators) for n in ast.walk(test))
+
+    seen = 0
+    for node in ast.walk(tree):
+        if isinstance(node, ast.If) and mentions_rank0(node.test):
+            for sub in node.body:
+                for call in ast.walk(sub):
+                    if isinstance(call, ast.Call) and isinstance(call.func, ast.Name) and call.func.id == "step":
+                        seen += 1
+                        kw = {k.arg: k.value for k in call.keywords}
+                        assert "gather" in kw and isinstance(kw["gather"], ast.Constant) and kw["gather"].value is False, \
+                            f"bench.py:{call.lineno}: rank-0-only step() must pass gather=False"
+    assert seen >= 4  # sd15 (2), extra workloads (1), sdxl / c5 (1)
