@@ -20,7 +20,11 @@ import os
 import sys
 import time
 
-import torch
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL otherwise fails with hipIpcGetMemHandle: invalid argument); the variable is
+# exported by the image already - set here as well so that a bare `python -m torch.distributed.run ... bench.py` cannot miss it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
