@@ -133,7 +133,12 @@ static __device__ __forceinline__ void rg_tile(const RingP& p, int L, int& tile_
   }
 }
 
-template <int WNT, bool GEGLU>
+// STAG (default): the two waves of a SIMD run a k-tile apart - waves 4-7 multiply k-tile u - 1 from fragments they kept in registers
+// across the barrier while waves 0-3 read k-tile u, and read k-tile u while waves 0-3 multiply it - and BOTH defer a tile's epilogue
+// (bias, GELU, stores: as many vector-ALU cycles as the tile's MFMAs for GEGLU) to behind the next barrier, where it runs beside the
+// partner's MFMAs instead of beside the partner's epilogue (MI355X_MICROARCH.md "Two waves per SIMD" item 9).  Same ring, same slots,
+// same results bit for bit.
+template <int WNT, bool GEGLU, bool STAG = true>
 __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(RingP p) {
   constexpr bool PAIR = !GEGLU;
   constexpr int WMT = 4, NW = 8, TM = 256, NSLOT = 3;
@@ -214,52 +219,36 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(RingP p) {
     issue(0);
     if (S_total > 1) issue(1);
   }
-  int u = 0;             // k-tile being multiplied (position in this block's sequence)
-  int extra = 0;         // stores of the previous tile's epilogue that the next two waits may leave in flight
-  int extra_ttl = 0;
-  for (int i = 0; i < my_tiles; ++i) {
+  // ---- pieces of the loop ----
+  bf16x8 xf0[WMT], wf0[WNT], xf1[WMT], wf1[WNT];
+  auto reads = [&](int u) {
+    const char* sl = smem + (u % NSLOT) * SLOT;
+#pragma unroll
+    for (int j = 0; j < WMT; ++j) xf0[j] = *reinterpret_cast<const bf16x8*>(sl + xoff[j]);
+#pragma unroll
+    for (int q = 0; q < WNT; ++q) wf0[q] = *reinterpret_cast<const bf16x8*>(sl + wb0 + q * 2048);
+#pragma unroll
+    for (int j = 0; j < WMT; ++j) xf1[j] = *reinterpret_cast<const bf16x8*>(sl + (xoff[j] ^ 64));
+#pragma unroll
+    for (int q = 0; q < WNT; ++q) wf1[q] = *reinterpret_cast<const bf16x8*>(sl + ((wb0 ^ 64) + q * 2048));
+  };
+  auto mma0 = [&]() {
+#pragma unroll
+    for (int q = 0; q < WNT; ++q)
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) acc[q][j] = CRG_MFMA_16x16x32(wf0[q], xf0[j], acc[q][j]);
+  };
+  auto mma1 = [&]() {
+#pragma unroll
+    for (int q = 0; q < WNT; ++q)
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) acc[q][j] = CRG_MFMA_16x16x32(wf1[q], xf1[j], acc[q][j]);
+  };
+  // epilogue of this block's i-th tile (exactly NST store instructions per wave), then the accumulators start over
+  auto epilogue = [&](int i) {
     int tile_m, tile_n;
     rg_tile(p, (int)blockIdx.x + i * G, tile_m, tile_n);
     const int m0 = tile_m * TM, n0 = tile_n * BN;
-    for (int kt = 0; kt < p.nk; ++kt, ++u) {
-      // top(u): k-tile u has landed once only what was requested after it - the batch of k-tile u + 1 (if any) and, for the first
-      // two k-tiles behind an epilogue, that epilogue's stores - is outstanding
-      rg_wait((u + 1 < S_total ? nload : 0) + (extra_ttl > 0 ? extra : 0));
-      if (extra_ttl > 0) --extra_ttl;
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const char* sl = smem + (u % NSLOT) * SLOT;
-      bf16x8 xf0[WMT], wf0[WNT], xf1[WMT], wf1[WNT];
-#pragma unroll
-      for (int j = 0; j < WMT; ++j) xf0[j] = *reinterpret_cast<const bf16x8*>(sl + xoff[j]);
-#pragma unroll
-      for (int q = 0; q < WNT; ++q) wf0[q] = *reinterpret_cast<const bf16x8*>(sl + wb0 + q * 2048);
-#pragma unroll
-      for (int j = 0; j < WMT; ++j) xf1[j] = *reinterpret_cast<const bf16x8*>(sl + (xoff[j] ^ 64));
-#pragma unroll
-      for (int q = 0; q < WNT; ++q) wf1[q] = *reinterpret_cast<const bf16x8*>(sl + ((wb0 ^ 64) + q * 2048));
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < WNT; ++q)
-#pragma unroll
-        for (int j = 0; j < WMT; ++j) acc[q][j] = CRG_MFMA_16x16x32(wf0[q], xf0[j], acc[q][j]);
-      __builtin_amdgcn_sched_barrier(0);
-      // the DMA batch of k-tile u + 2 goes out BEHIND the first MFMA block (its address arithmetic and 1 KiB pieces then issue under
-      // the matrix pipe's backlog instead of in front of the fragment reads); its slot held k-tile u - 1, which every wave finished
-      // reading before this k-tile's barrier
-      if (u + 2 < S_total) {
-        __builtin_amdgcn_s_setprio(2);
-        issue(u + 2);
-        __builtin_amdgcn_s_setprio(0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < WNT; ++q)
-#pragma unroll
-        for (int j = 0; j < WMT; ++j) acc[q][j] = CRG_MFMA_16x16x32(wf1[q], xf1[j], acc[q][j]);
-    }
-    // ---- epilogue of tile i (the next tile's first k-tiles are landing underneath): exactly NST store instructions per wave ----
     const int nb = n0 + wn * (16 * WNT);
     if constexpr (GEGLU) {
 #pragma unroll
@@ -336,12 +325,86 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(RingP p) {
         }
       }
     }
-    extra = NST;
-    extra_ttl = 2;
 #pragma unroll
     for (int q = 0; q < WNT; ++q)
 #pragma unroll
       for (int j = 0; j < WMT; ++j) acc[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto top = [&](int u, int& ttl) {  // k-tile u landed (the batch requested after it and, behind an epilogue, its stores stay in flight); barrier
+    rg_wait((u + 1 < S_total ? nload : 0) + (ttl > 0 ? NST : 0));
+    if (ttl > 0) --ttl;
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  if constexpr (!STAG) {
+    int u = 0, ttl = 0;
+    for (int i = 0; i < my_tiles; ++i) {
+      for (int kt = 0; kt < p.nk; ++kt, ++u) {
+        top(u, ttl);
+        reads(u);
+        __builtin_amdgcn_sched_barrier(0);
+        mma0();
+        __builtin_amdgcn_sched_barrier(0);
+        // the DMA batch of k-tile u + 2 goes out BEHIND the first MFMA block; its slot held k-tile u - 1, which every wave finished
+        // reading before this k-tile's barrier
+        if (u + 2 < S_total) {
+          __builtin_amdgcn_s_setprio(2);
+          issue(u + 2);
+          __builtin_amdgcn_s_setprio(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma1();
+      }
+      epilogue(i);  // the next tile's first k-tiles are landing underneath
+      ttl = 2;
+    }
+  } else if (wave < 4) {
+    // waves 0-3: barrier | epilogue of the previous tile (first k-tile of a tile) | read u | multiply u (issue u + 2 in between)
+    int u = 0, ttl = 0;
+    for (int i = 0; i < my_tiles; ++i) {
+      for (int kt = 0; kt < p.nk; ++kt, ++u) {
+        top(u, ttl);
+        if (kt == 0 && i > 0) {
+          epilogue(i - 1);  // its stores precede the batch of k-tile u + 2: only the next wait has to leave them in flight
+          ttl = 1;
+        }
+        reads(u);
+        __builtin_amdgcn_sched_barrier(0);
+        mma0();
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 2 < S_total) issue(u + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma1();
+      }
+    }
+    if (my_tiles > 0) epilogue(my_tiles - 1);
+  } else {
+    // waves 4-7: barrier | multiply u - 1 (fragments in registers) | issue u + 2 | epilogue if u - 1 closed a tile | read u
+    int u = 0, ttl = 0;
+    for (int i = 0; i < my_tiles; ++i) {
+      for (int kt = 0; kt < p.nk; ++kt, ++u) {
+        top(u, ttl);
+        if (u > 0) {
+          mma0();
+          mma1();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 2 < S_total) issue(u + 2);
+        if (kt == 0 && i > 0) {
+          epilogue(i - 1);  // behind the batch of k-tile u + 2: the next TWO waits leave the stores in flight
+          ttl = 2;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        reads(u);
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the reads have returned before the next barrier lets the slot be refilled
+      }
+    }
+    if (my_tiles > 0) {
+      mma0();
+      mma1();
+      epilogue(my_tiles - 1);
+    }
   }
 }
 
@@ -406,7 +469,9 @@ int launch_gemm_ring(crg_ctx* ctx, hipStream_t st, const GemmP& g, double flops,
   int grid = ctx->n_cu > 0 ? ctx->n_cu : 256;
   grid &= ~7;  // a block's tile ids must stay on one XCD label
   if (grid > p.tile_count) grid = p.tile_count;
-  void (*kern)(RingP) = geglu ? gemm_ring_kernel<4, true> : (wnt == 5 ? gemm_ring_kernel<5, false> : gemm_ring_kernel<4, false>);
+  static const int stag = getenv("CRG_GEMM_RING_STAG") ? atoi(getenv("CRG_GEMM_RING_STAG")) : 1;  // dev knob: 0 = all eight waves in lockstep (round 3a)
+  void (*kern)(RingP) = stag ? (geglu ? gemm_ring_kernel<4, true> : (wnt == 5 ? gemm_ring_kernel<5, false> : gemm_ring_kernel<4, false>))
+                             : (geglu ? gemm_ring_kernel<4, true, false> : (wnt == 5 ? gemm_ring_kernel<5, false, false> : gemm_ring_kernel<4, false, false>));
   const size_t lds = (size_t)3 * (256 * 128 + bn * 128);
   if (int rc = crg_set_dyn_lds(ctx, reinterpret_cast<const void*>(kern), 160 * 1024, "gemm ring")) return rc;
   crg_prof_scope ps(ctx, st, wnt == 5 ? CRG_K_GEMM_W5 : CRG_K_GEMM_W4, flops, bytes);
