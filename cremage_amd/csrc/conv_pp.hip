@@ -483,6 +483,52 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(GemmP p) {
     mma();
     mma1();
   };
+  // SCHED 2: the interval's DMA pieces one at a time BETWEEN the MFMA groups (four MFMAs of one weight fragment each), so that a
+  // wave never sits in a burst of piece issues (the queue in front of the texture addresser is shared by the CU: a burst of four to
+  // eight pieces stalls the issuing wave for 100 - 185 cycles each, and in series with its MFMAs and fragment reads that burst is on
+  // the wave's critical path through the interval)
+  auto mma2_spread = [&](int g, int tt, auto KWc, bool on) {
+    constexpr int kw = decltype(KWc)::value;
+    if constexpr (LIN && kw != 1) {
+#pragma unroll
+      for (int j = 0; j < WMT; ++j)
+        if ((edge >> (kw == 0 ? j : 8 + j)) & 1u) { xf[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xf1[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+    }
+    XGroup xg{};
+    if constexpr (kw == 0) { if (on) xg = x_group(g + 1); }
+    auto piece = [&](auto Kc) {  // slot k of the interval: row-buffer pieces first (first k-tile of a group), then the weight pieces
+      constexpr int k = decltype(Kc)::value;
+#ifndef CRG_ABL_NODMA
+      if (on) {
+        if constexpr (kw == 0) {
+          if constexpr (k < XI) x_piece(k, xg);
+          else if constexpr (k - XI < WL) w_piece(k - XI, tt + 3);
+        } else {
+          if constexpr (k < WL) w_piece(k, tt + 3);
+        }
+      }
+#endif
+    };
+    auto grp = [&](const bf16x8 (&x4)[WMT], const bf16x8& w1, auto Ic) {
+      constexpr int i = decltype(Ic)::value;
+#ifdef CRG_ABL_NOMMA
+      asm volatile("" ::"v"(w1));
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) asm volatile("" ::"v"(x4[j]));
+#else
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) acc[i][j] = CRG_MFMA_16x16x32(w1, x4[j], acc[i][j]);
+#endif
+    };
+    using std::integral_constant;
+#define PP_G(XA, WA, I, K) grp(XA, WA[I], integral_constant<int, I>{}); PP_SB; piece(integral_constant<int, K>{}); PP_SB;
+    PP_G(xf, wf, 0, 0) PP_G(xf, wf, 1, 1) PP_G(xf, wf, 2, 2) PP_G(xf, wf, 3, 3)
+    if constexpr (WNT > 4) { PP_G(xf, wf, 4, 4) }
+    PP_G(xf1, wf1, 0, 5) PP_G(xf1, wf1, 1, 6) PP_G(xf1, wf1, 2, 7) PP_G(xf1, wf1, 3, 8)
+    if constexpr (WNT > 4) { PP_G(xf1, wf1, 4, 9) }
+#undef PP_G
+    if constexpr (WNT <= 4) { piece(integral_constant<int, 4>{}); piece(integral_constant<int, 9>{}); }
+  };
   // wait at the end of interval tt: leaves in flight what the interval itself issued
   auto end_wait = [&](auto KWc, auto STEADYc) {
     constexpr int kw = decltype(KWc)::value;
@@ -510,16 +556,16 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(GemmP p) {
     if constexpr (GB) {
       reads(g, tt, KWc);
       PP_SB;
-      if constexpr (STEADY) issue(g, tt, KWc, true, true);
+      if constexpr (SCHED != 2) { if constexpr (STEADY) issue(g, tt, KWc, true, true); }
       if constexpr (LASTT) fetch_res();
       PP_SB;
-      mma2(KWc);
+      if constexpr (SCHED == 2) mma2_spread(g, tt, KWc, STEADY); else mma2(KWc);
       PP_SB;
       if constexpr (!LASTT) end_wait(KWc, STEADYc);
     } else {
-      mma2(KWc);
+      if constexpr (SCHED == 2) mma2_spread(g, tt, KWc, STEADY); else mma2(KWc);
       PP_SB;
-      if constexpr (STEADY) issue(g, tt, KWc, true, true);
+      if constexpr (SCHED != 2) { if constexpr (STEADY) issue(g, tt, KWc, true, true); }
       if constexpr (LASTT) fetch_res();
       if constexpr (!LASTT) {
         reads(kw == 2 ? g + 1 : g, tt + 1, KN{});
@@ -590,8 +636,8 @@ int launch_conv_pp(crg_ctx* ctx, hipStream_t st, const GemmP& p, int wnt, int sc
   const bool lin = p.halo_lin != 0;
 #define CRG_PP_PICK(W, S) (p.pair ? (lin ? conv3_pp_kernel<W, true, true, S> : conv3_pp_kernel<W, true, false, S>) \
                                   : (lin ? conv3_pp_kernel<W, false, true, S> : conv3_pp_kernel<W, false, false, S>))
-  if (wnt == 5) kern = sched ? CRG_PP_PICK(5, 1) : CRG_PP_PICK(5, 0);
-  else if (wnt == 4) kern = sched ? CRG_PP_PICK(4, 1) : CRG_PP_PICK(4, 0);
+  if (wnt == 5) kern = sched == 2 ? CRG_PP_PICK(5, 2) : sched ? CRG_PP_PICK(5, 1) : CRG_PP_PICK(5, 0);
+  else if (wnt == 4) kern = sched == 2 ? CRG_PP_PICK(4, 2) : sched ? CRG_PP_PICK(4, 1) : CRG_PP_PICK(4, 0);
   else return crg_fail(ctx, -22, "conv pp: unsupported tile width %d", wnt);
 #undef CRG_PP_PICK
   const int BN = 32 * wnt, TP = 256;

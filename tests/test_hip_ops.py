@@ -411,7 +411,7 @@ def test_conv_gn_fused(N, C1, C2, H, W, Co, res):
 
 def test_conv_schedules():
     """The 256-pixel-tile 3x3 conv under every schedule the library carries, each in a child process (CRG_RING is read once per
-    process): 6 = staggered waves (conv_pp.hip, the default), 5 = its 4-barrier ping-pong form, 2 = the deep-ring kernel of round 2
+    process): 6 = staggered waves (conv_pp.hip, the default), 7 = the same with the DMA pieces threaded between the MFMA groups, 5 = the 4-barrier ping-pong form, 2 = the deep-ring kernel of round 2
     (conv_ring.hip), 0 = the 2-stage 256-row row-halo kernel.  All of them accumulate every output in the same order (same tile,
     same K slices, same split-K reduce), so beyond matching the fp32 reference they must agree BITWISE with each other."""
     import json
@@ -420,7 +420,7 @@ def test_conv_schedules():
     import sys
     from tests.conftest import REPO
     results = {}
-    for ring in ("6", "5", "2", "0"):
+    for ring in ("6", "7", "5", "2", "0"):
         env = dict(os.environ, CRG_RING=ring)
         r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_conv_sched_run.py")], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (ring, r.stderr[-3000:])
