@@ -30,7 +30,9 @@ def main():
     # tiles, two image rows per tile, row segments
     for (N, C1, C2, H, W, Co, up) in [(8, 320, 0, 64, 64, 320, False), (8, 320, 320, 64, 64, 320, False), (8, 640, 0, 32, 32, 640, False),
                                       (8, 1280, 0, 16, 16, 1280, False), (8, 1280, 0, 8, 8, 1280, False), (8, 640, 0, 32, 32, 640, True),
-                                      (8, 192, 64, 64, 64, 128, False), (2, 128, 0, 128, 128, 320, False), (1, 128, 0, 64, 512, 320, False)]:
+                                      (8, 192, 64, 64, 64, 128, False), (2, 128, 0, 128, 128, 320, False), (1, 128, 0, 64, 512, 320, False),
+                                      (8, 64, 0, 64, 64, 160, False),    # three (chunk, kernel row) groups cut into K slices of two and ONE group: a slice that is all prologue + last group
+                                      (4, 64, 0, 64, 64, 320, False)]:   # three groups, no split: one steady group
         C = C1 + C2
         x = rnd(N, C1, H, W, seed=180)
         x2 = rnd(N, C2, H, W, seed=181) if C2 else None

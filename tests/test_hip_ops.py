@@ -425,7 +425,7 @@ def test_conv_schedules():
         r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_conv_sched_run.py")], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (ring, r.stderr[-3000:])
         results[ring] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("CONV_SCHED_RESULT ")][-1][len("CONV_SCHED_RESULT "):])
-    assert len(results["6"]) == 9
+    assert len(results["6"]) == 11
     for ring, res in results.items():
         for case, (rel, digest) in res.items():
             assert rel < 6e-3, (ring, case, rel)
