@@ -1614,10 +1614,11 @@ int launch_planes(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
   constexpr int BN = 32 * WNT;
   constexpr size_t lds = (size_t)2 * 2 * (128 + BN) * 128 + 1024;
   p.zero_page = (const bf16*)ctx->zero_page;
-  if (p.gstat) return crg_fail(ctx, -22, "gemm/conv: GroupNorm statistics are a bf16-path feature");
+  if (p.gstat && (batch != 1 || (p.N & 3) || (p.M & 31) || (p.ldy & 3)))
+    return crg_fail(ctx, -22, "gemm/conv: GroupNorm statistics need an unbatched problem with N %% 4 == 0 and M %% 32 == 0");
   p.tiles_n = (p.N + BN - 1) / BN;
   p.tiles_m = (p.M + 127) / 128;
-  p.splits = choose_splits(p, p.tiles_n * p.tiles_m, batch);
+  p.splits = p.gstat ? 1 : choose_splits(p, p.tiles_n * p.tiles_m, batch);  // the statistics come out of the epilogue: no K split
   if (p.splits > 1) {
     p.slab = (float*)crg_scratch(ctx, (size_t)batch * p.splits * p.M * p.N * sizeof(float));
     if (!p.slab) return crg_fail(ctx, -12, "gemm: out of scratch for %d split-K slabs", p.splits);
@@ -1674,8 +1675,11 @@ int launch_wnt(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
 
 template <bool CONV>
 int dispatch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, int a_dtype, int y_dtype, int prec, Work wk) {
-  if (p.gstat && !(prec == CRG_PREC_BF16 && a_dtype == CRG_BF16 && y_dtype == CRG_BF16 && batch == 1 && p.epi != CRG_EPI_GEGLU && (p.N & 7) == 0))
-    return crg_fail(ctx, -22, "gemm/conv: GroupNorm statistics need bf16 in / out, batch 1, N %% 8 == 0 and a plain epilogue");
+  // GroupNorm statistics: the bf16 path (paired epilogue / split-K reduce), or the fp32-class conv on pre-split planes (its fp32 epilogue)
+  const bool gstat_bf16 = prec == CRG_PREC_BF16 && a_dtype == CRG_BF16 && y_dtype == CRG_BF16 && (p.N & 7) == 0;
+  const bool gstat_planes = prec == CRG_PREC_BF16X3 && a_dtype == CRG_BF16 && y_dtype == CRG_F32 && p.a_lo && !p.a_is_weight && (p.N & 3) == 0;
+  if (p.gstat && !((gstat_bf16 || gstat_planes) && batch == 1 && p.epi == CRG_EPI_NONE))
+    return crg_fail(ctx, -22, "gemm/conv: GroupNorm statistics need bf16 in / out (N %% 8 == 0) or pre-split planes in / fp32 out (N %% 4 == 0), batch 1 and a plain epilogue");
   if (prec == CRG_PREC_BF16) {
     if (a_dtype == CRG_BF16 && y_dtype == CRG_BF16) return launch_wnt<1, bf16, bf16, CONV>(ctx, st, p, batch, wk);
     if (a_dtype == CRG_BF16 && y_dtype == CRG_F32) return launch_wnt<1, bf16, float, CONV>(ctx, st, p, batch, wk);

@@ -81,7 +81,22 @@ __device__ __forceinline__ void block_to_tile(const GemmP& p, int& tile_m, int& 
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
+// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), result in every lane: pure VALU (quad permutes, then the two row
+// mirrors), no LDS crossbar
+__device__ __forceinline__ float row16_sum(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+#endif
+  return v;
+}
+
 // ---- shared epilogue: lane holds rows n = ..+fq*4+{0..3}, column m = ..+frow of each 16x16 tile ----
+// fp32 outputs with p.gstat set (the fp32-class VAE convs, round 3): per 32-row block and channel the sum and the sum of squares of the
+// stored values go to the statistics side channel (planes as in the bf16 path), so that the GroupNorm behind the conv
+// (model.py:99-113 -> :116-121 of the next ResnetBlock) does not read the fp32 tensor - up to 1 GB - once more for them.
 template <int WNT, typename YT, int WMT = 4>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][WMT], int m0, int n0, int wm, int wn, int frow, int fq,
                                               int bz, int sid, const bf16x4 (&pre)[WNT][WMT], bool use_pre,
@@ -107,9 +122,39 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][
   }
   YT* Y = reinterpret_cast<YT*>(p.y) + (long)bz * p.y_bs;
   const YT* R = p.res ? reinterpret_cast<const YT*>(p.res) + (long)bz * p.r_bs : nullptr;
+  constexpr bool CAN_STATS = sizeof(YT) == 4 && (WMT % 2 == 0);
+  const bool do_stats = CAN_STATS && p.gstat != nullptr;
+  f32x4 gs1[CAN_STATS ? WNT : 1], gs2[CAN_STATS ? WNT : 1];
+  auto flush_stats = [&](int jb) {  // rows of the tile pair (jb, jb + 1): fold the 16 lanes of each DPP row, lane frow == 0 stores
+    if constexpr (CAN_STATS) {
+      const int row0 = m0 + wm * (16 * WMT) + jb * 16;
+      const long rb = row0 >> 5;
+#pragma unroll
+      for (int i = 0; i < WNT; ++i) {
+        f32x4 a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] = row16_sum(gs1[i][e]);
+          b[e] = row16_sum(gs2[i][e]);
+        }
+        const int n = n0 + wn * (16 * WNT) + i * 16 + fq * 4;
+        if (frow == 0 && n + 4 <= p.N && row0 < p.M) {
+          *reinterpret_cast<f32x4*>(p.gstat + rb * p.N + n) = a;
+          *reinterpret_cast<f32x4*>(p.gstat + p.gstat_plane + rb * p.N + n) = b;
+        }
+      }
+    }
+  };
 #pragma unroll
   for (int j = 0; j < WMT; ++j) {
     const int m = m0 + wm * (16 * WMT) + j * 16 + frow;
+    if constexpr (CAN_STATS) {
+      if (do_stats && (j & 1) == 0) {
+        if (j > 0) flush_stats(j - 2);
+#pragma unroll
+        for (int i = 0; i < WNT; ++i) gs1[i] = gs2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
     if (m >= p.M) continue;
     const float brow = (p.bias_mode == CRG_BIAS_ROW) ? p.bias[m] : 0.f;
     const float* cv = p.cvec ? p.cvec + (long)(m / p.cvec_rows) * p.cvec_ld : nullptr;
@@ -170,6 +215,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][
             for (int e = 0; e < 4; ++e) v[e] += (float)rp[e];
           }
         }
+        if constexpr (CAN_STATS) {
+          if (do_stats) {
+            gs1[i] += v;
+            gs2[i] += v * v;
+          }
+        }
         if (((p.ldy | n) & 3) == 0) {
           if constexpr (sizeof(YT) == 2) {
             bf16x4 o4;
@@ -196,6 +247,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][
       }
     }
   }
+  if constexpr (CAN_STATS) {
+    if (do_stats) flush_stats(WMT - 2);
+  }
 }
 
 // ---- paired output columns -------------------------------------------------------------------------------------------
@@ -217,17 +271,6 @@ __device__ __forceinline__ int unpair_col(int pos) {  // LDS row position within
 
 // r2[u][j] / r1[j] / bpre[i]: residual (16 bytes per tile pair, 8 for an odd last tile) and bias of this lane in the paired
 // mapping, fetched ahead of the K loop (has_res / has_bias say whether they were).
-// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), result in every lane: pure VALU (quad permutes, then the two row
-// mirrors), no LDS crossbar
-__device__ __forceinline__ float row16_sum(float v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
-#endif
-  return v;
-}
 
 // SM: 0 = this instantiation never emits GroupNorm statistics, 1 = always (p.gstat is set), 2 = decided at run time.  The statistics
 // path keeps ~40 more values live; compiled into the two-blocks-per-CU GEMM kernel as a runtime branch it pushed that kernel from

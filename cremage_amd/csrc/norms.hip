@@ -648,6 +648,40 @@ extern "C" int crg_groupnorm_pre(crg_ctx* ctx, void* stream, const void* x, cons
   return 0;
 }
 
+extern "C" int crg_groupnorm_pre_split(crg_ctx* ctx, void* stream, const void* x, const float* stats, const float* gamma, const float* beta,
+                                       void* y_hi, void* y_lo, int N, int HW, int C, int groups, float eps, int fuse_silu) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, N > 0 && HW > 0 && C > 0 && x && stats, "groupnorm_pre_split: empty input");
+  CRG_REQUIRE(ctx, y_hi && y_lo && (((uintptr_t)y_hi | (uintptr_t)y_lo | (uintptr_t)x | (uintptr_t)stats) & 15) == 0, "groupnorm_pre_split: pointers must be 16-byte aligned");
+  CRG_REQUIRE(ctx, groups > 0 && groups <= GN_MAX_GROUPS && C % groups == 0, "groupnorm_pre_split: groups=%d C=%d unsupported", groups, C);
+  CRG_REQUIRE(ctx, C % 8 == 0 && (C >> 3) <= 512, "groupnorm_pre_split: C=%d must be a multiple of 8 and <= 4096", C);
+  CRG_REQUIRE(ctx, HW % 32 == 0, "groupnorm_pre_split: HW=%d must be a multiple of the 32-row statistics blocks", HW);
+  CRG_REQUIRE(ctx, C / groups <= 128, "groupnorm_pre_split: group size %d unsupported (<= 128)", C / groups);
+  const long rbs = (long)N * (HW >> 5);
+  float* mr = (float*)crg_scratch(ctx, (size_t)N * groups * 2 * sizeof(float));
+  if (!mr) return crg_fail(ctx, -12, "groupnorm_pre_split: out of scratch");
+  hipStream_t st = (hipStream_t)stream;
+  const double elems = (double)N * HW * C;
+  {
+    crg_prof_scope ps(ctx, st, CRG_K_GN_STATS, 2.0 * rbs * C, 8.0 * rbs * C);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, st, stats, (const float*)nullptr, C, C, HW, groups, rbs * C, 0L, eps, mr);
+  }
+  {
+    const int threads = (C >> 3) <= 256 ? 256 : 512;
+    int chunks = HW / 64;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 256) chunks = 256;
+    while ((long)chunks * N < 512 && chunks * 8 <= HW && chunks < 256) chunks *= 2;
+    const int rpc = (HW + chunks - 1) / chunks;
+    chunks = (HW + rpc - 1) / rpc;
+    crg_prof_scope ps(ctx, st, CRG_K_GN_APPLY, 5.0 * elems, elems * 8.0);
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(chunks, N), dim3(threads), 0, st, (const float*)x, (const float*)nullptr, C, C, HW, groups, rpc, -1,
+                       mr, (const float*)nullptr, gamma, beta, eps, fuse_silu, (float*)nullptr, (bf16*)y_hi, (bf16*)y_lo);
+  }
+  CRG_CHECK_LAUNCH(ctx, "groupnorm_pre_split");
+  return 0;
+}
+
 extern "C" int crg_groupnorm_split(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* gamma,
                                    const float* beta, void* y_hi, void* y_lo, int N, int HW, int C, int groups, float eps,
                                    int fuse_silu) {

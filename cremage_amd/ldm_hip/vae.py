@@ -39,7 +39,7 @@ class Upsample(nn.Module):
         # first (one elementwise pass) so that the conv runs on the LDS-DMA kernel
         if _planes_ok(x, self.conv):
             hi, lo = ops.split_bf16(x)
-            return self.conv(hi, x_lo=lo, upsample2x=True)
+            return self.conv(hi, x_lo=lo, upsample2x=True, gn_stats=True)  # feeds the next ResnetBlock's norm1
         return self.conv(x, upsample2x=True)
 
 
@@ -83,11 +83,11 @@ class ResnetBlock(nn.Module):
         if _planes_ok(x, self.conv1) and _planes_ok(x, self.conv2):
             # fp32-class: GroupNorm+swish writes the two bf16 planes the conv's LDS-DMA kernel stages (no fp32 round trip)
             hi, lo = self.norm1(x, silu=True, split=True)
-            h = self.conv1(hi, x_lo=lo)
+            h = self.conv1(hi, x_lo=lo, gn_stats=True)  # statistics for norm2 out of the conv's epilogue
             hi, lo = self.norm2(h, silu=True, split=True)
             if self.in_channels != self.out_channels:
                 x = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x)
-            return self.conv2(hi, x_lo=lo, residual=x)
+            return self.conv2(hi, x_lo=lo, residual=x, gn_stats=True)  # ... for the next block's norm1 / norm_out
         h = self.conv1(self.norm1(x, silu=True))
         h = self.norm2(h, silu=True)
         if self.in_channels != self.out_channels:

@@ -151,12 +151,13 @@ def clear_weight_cache():
 # ControlNet's in-place residual adds, cldm.py:57-65, invalidate it) and then skips its statistics pass over the tensor.
 GN_STATS = __import__("os").environ.get("CRG_GN_STATS", "1") != "0"  # dev knob: 0 = every GroupNorm computes its own statistics
 GN_STATS_MIN_HW = 512  # smaller images take the single-launch GroupNorm kernel, which reads the tensor once anyway
+VAE_GN_STATS = __import__("os").environ.get("CRG_VAE_GN_STATS", "1") != "0"  # dev knob: 0 = the fp32-class convs emit no statistics
 
 
 def _gn_stats_buffer(rows: int, cols: int, hw: Optional[int], in_dtype, out_dtype, device) -> Optional[torch.Tensor]:
     if not GN_STATS or not hw or hw % 32 or hw < GN_STATS_MIN_HW or rows % hw or cols % 8:
         return None
-    if in_dtype != HALF or out_dtype != HALF:
+    if in_dtype != HALF or out_dtype not in (HALF, torch.float32):  # fp32 outputs: the fp32-class conv on split planes (VAE)
         return None
     return torch.empty((2, (rows + 31) // 32, cols), dtype=torch.float32, device=device)
 
@@ -296,6 +297,11 @@ def group_norm(x: torch.Tensor, weight, bias, groups: int, eps: float, silu: boo
         if x.dtype != torch.float32:
             raise L.CrgError("group_norm(split=True) is the fp32-class path: fp32 input expected")
         hi, lo = empty_image(n, c, hh, ww, HALF, x.device), empty_image(n, c, hh, ww, HALF, x.device)
+        st1 = _gn_stats_of(x, hh * ww) if x2 is None else None
+        if st1 is not None:  # statistics handed over by the fp32-class conv that produced x: no statistics pass over the fp32 tensor
+            L.check(L.load().crg_groupnorm_pre_split(h, _st(), _p(x), _p(st1), _p(f32_vec(weight)), _p(f32_vec(bias)), _p(hi), _p(lo), n, hh * ww, c,
+                                                     groups, eps, int(silu)), h, "crg_groupnorm_pre_split")
+            return hi, lo
         L.check(L.load().crg_groupnorm_split(h, _st(), _p(x), _p(x2), c1, _p(f32_vec(weight)), _p(f32_vec(bias)), _p(hi), _p(lo), n, hh * ww, c,
                                              groups, eps, int(silu)), h, "crg_groupnorm_split")
         return hi, lo
@@ -597,7 +603,9 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         keep = (f32_vec(gw), f32_vec(gb))
         a.gn_gamma, a.gn_beta, a.gn_y = keep[0].data_ptr(), keep[1].data_ptr(), y_norm.data_ptr()
         a.gn_groups, a.gn_silu, a.gn_eps = int(groups), int(bool(silu)), float(eps)
-    stats = _gn_stats_buffer(n * ho * wo, cout, ho * wo, x.dtype, y.dtype, x.device) if (gn_stats and not planes and gn is None) else None
+    stats = _gn_stats_buffer(n * ho * wo, cout, ho * wo, x.dtype, y.dtype, x.device) if (gn_stats and gn is None and (planes or x.dtype == HALF)) else None
+    if stats is not None and planes and (cout % 4 or VAE_GN_STATS is False):
+        stats = None
     if stats is not None:
         a.gn_stats = stats.data_ptr()
     h = _h(x)

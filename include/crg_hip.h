@@ -104,6 +104,12 @@ int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const void* x2, int
 int crg_groupnorm_split(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* gamma,
                         const float* beta, void* y_hi, void* y_lo, int N, int HW, int C, int groups, float eps,
                         int fuse_silu);
+/* crg_groupnorm_split for an fp32 input whose PRODUCER handed over its statistics (round 3: the fp32-class convs of the VAE emit them from
+ * their epilogue like the bf16 path does, crg_conv_args.gn_stats with y_dtype = CRG_F32): `stats` = fp32 [2][N * HW / 32][C], plane 0 the
+ * per 32-row block and channel sums of the conv's outputs, plane 1 of their squares.  Replaces the same `Normalize` + swish
+ * (model.py:116-121 / :99-113) without the statistics pass over the fp32 tensor. */
+int crg_groupnorm_pre_split(crg_ctx* ctx, void* stream, const void* x, const float* stats, const float* gamma, const float* beta,
+                            void* y_hi, void* y_lo, int N, int HW, int C, int groups, float eps, int fuse_silu);
 /* GroupNorm (+SiLU) whose STATISTICS come from the producer of x (and of x2): the conv / GEMM launch that wrote the tensor also wrote
  * `gn_stats` (crg_conv_args / crg_gemm_args): per 32-row block and channel the sum and the sum of squares of its rounded outputs,
  * planes [2][N * HW / 32][C1].  This call folds them per (sample, group) - one tiny launch instead of a read of the whole tensor -
