@@ -460,6 +460,36 @@ def test_conv_rowhalo_planes(N, C, H, W, Co):
         assert err < 3e-5 * max(1.0, ref.abs().max().item()), (N, C, H, W, Co, with_res, err)
 
 
+@pytest.mark.parametrize("N,C,H,W,Co,with_res", [(2, 128, 32, 32, 128, False), (1, 64, 16, 128, 256, True), (2, 256, 64, 64, 128, True)])
+def test_conv_planes_gn_stats(N, C, H, W, Co, with_res):
+    """fp32-class conv on split planes with the GroupNorm statistics side channel (fp32 epilogue), then crg_groupnorm_pre_split: the
+    statistics planes equal the per-32-row-block sums of the conv's own output, and the normalised planes equal GroupNorm + swish of it
+    (fp64 reference) as closely as the path that reads the tensor for its statistics."""
+    from cremage_amd import ops
+    x = rnd(N, C, H, W, seed=190, scale=2.0) + 0.5
+    w, b = rnd(Co, C, 3, 3, seed=191, scale=(9 * C) ** -0.5), rnd(Co, seed=192) + 1.5  # a mean well away from zero
+    res = rnd(N, Co, H, W, seed=193)
+    g, be = (1 + 0.1 * rnd(Co, seed=194)).to(_dev()), (0.1 * rnd(Co, seed=195)).to(_dev())
+    hi, lo = ops.split_bf16(nhwc(x, torch.float32))
+    y = ops.conv2d(hi, w.to(_dev()), b.to(_dev()), x_lo=lo, residual=nhwc(res, torch.float32) if with_res else None, gn_stats=True)
+    st = getattr(y, "_crg_gn", None)
+    assert st is not None, "the planes conv did not attach its statistics"
+    rows = y.permute(0, 2, 3, 1).reshape(-1, Co).double()                      # [M][Co] in the kernel's row order
+    blk = rows.reshape(-1, 32, Co)
+    assert (st[0][0].double() - blk.sum(1)).abs().max().item() < 2e-4 * max(1.0, blk.sum(1).abs().max().item())
+    assert (st[0][1].double() - (blk * blk).sum(1)).abs().max().item() < 2e-4 * max(1.0, (blk * blk).sum(1).abs().max().item())
+    nh, nl = ops.group_norm(y, g, be, 32, 1e-6, silu=True, split=True)          # consumes the statistics
+    y2 = y.clone()                                                             # same values, no side channel: the statistics kernel
+    rh, rl = ops.group_norm(y2, g, be, 32, 1e-6, silu=True, split=True)
+    ref = F.silu(F.group_norm(y.double().cpu(), 32, g.double().cpu(), be.double().cpu(), 1e-6))
+    e_pre = ((nh.float() + nl.float()).double().cpu() - ref).abs().max().item()
+    e_ref = ((rh.float() + rl.float()).double().cpu() - ref).abs().max().item()
+    assert e_pre < 1e-4 and e_pre < 1.5 * e_ref + 1e-6, (e_pre, e_ref)  # the planes' own resolution (hi + lo: 2^-17 relative) bounds both
+    st[0].zero_()                                                              # ... and the side channel really is what was consumed
+    zh, _ = ops.group_norm(y, g, be, 32, 1e-6, silu=True, split=True)
+    assert not torch.equal(zh, nh)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_unet_shapes(dtype):
     """production channel counts at small spatial size (tile tails in both M and N)"""
