@@ -96,12 +96,17 @@ def main():
     def fresh_x0():
         return torch.stack([torch.randn((4, 64, 64), generator=g, device=dev) for g in gens])
 
-    def noise_sampler(sigma, sigma_next):
-        return torch.stack([torch.randn((4, 64, 64), generator=g, device=dev) for g in gens])
-
     def step(gather=True):
+        # the ancestral noise of the whole trajectory is drawn up front, one randn per image generator (per-image seeds as before):
+        # the same number of Gaussian samples inside the timed region, in 4 launches instead of 4 per sampler step
+        if os.environ.get("CRG_BENCH_STEP_NOISE") == "1":  # dev knob (A/B): one draw per image and sampler step, as in round 2
+            ns = lambda sigma, sigma_next: torch.stack([torch.randn((4, 64, 64), generator=g, device=dev) for g in gens])
+        else:
+            noise = torch.stack([torch.randn((a.sampler_steps, 4, 64, 64), generator=g, device=dev) for g in gens], dim=1)
+            draws = iter(range(a.sampler_steps))
+            ns = lambda sigma, sigma_next: noise[next(draws)]
         images, _ = P.txt2img(ldm, c, uc, steps=a.sampler_steps, sampler=a.sampler, cfg_scale=7.5, height=512, width=512,
-                              x0=fresh_x0(), noise_sampler=noise_sampler)
+                              x0=fresh_x0(), noise_sampler=ns)
         # gather=False: the rank-0-only profiling steps behind the timed region must not enter a collective the other ranks never join
         return D.all_gather_batch(images) if gather else images
 

@@ -18,6 +18,9 @@ import numpy as np
 import torch
 from torch import nn
 
+# dev knob: 0 = the fused sampler steps compute the CompVis wrapper's scalings and timestep per step (round 2) instead of once per run
+STEP_TABLES = __import__("os").environ.get("CRG_SAMPLER_TABLES", "1") != "0"
+
 
 def append_zero(x):
     """x followed by one 0 (the terminal sigma of every k-diffusion schedule)."""
@@ -169,6 +172,21 @@ class LDMWrapperForKDiffusion(nn.Module):
         _, c_in = [append_dims(v, x_in.ndim) for v in cv.get_scalings(sigma_in)]
         return cv.get_eps(x_in * c_in, cv.sigma_to_t(sigma_in), cond=self._cat_cond())
 
+    def eps_tables(self, sigmas):
+        """(c_in, t) of the CompVis wrapper for a whole vector of sigmas at once - the same elementwise arithmetic
+        CompVisDenoiser.forward (external.py:111-114) performs per step on the batch-expanded sigma, so the values are identical;
+        computed once per sampling run they replace ~25 tiny launches per step (scalings, log / searchsorted / blend of sigma_to_t)."""
+        cv = self.compviz_model
+        _, c_in = cv.get_scalings(sigmas)
+        return c_in, cv.sigma_to_t(sigmas)
+
+    def eps_pair_pre(self, x, c_in_i, t_row):
+        """eps_pair with the step's scalars taken from eps_tables: `c_in_i` a 0-dim device tensor, `t_row` the step's timestep
+        already expanded to the doubled batch.  ONE elementwise launch builds cat([x] * 2) * c_in."""
+        xx = torch.empty((2,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        torch.mul(x.unsqueeze(0).expand_as(xx), c_in_i, out=xx)
+        return self.compviz_model.get_eps(xx.view((2 * x.shape[0],) + tuple(x.shape[1:])), t_row, cond=self._cat_cond())
+
     def fused_step_ok(self, x) -> bool:
         return (self.unconditional_conditioning is not None and self.unconditional_guidance_scale != 1. and x.is_cuda
                 and x.dtype == torch.float32 and isinstance(self.compviz_model, CompVisDenoiser))
@@ -220,8 +238,13 @@ def sample_euler(model, x, sigmas, extra_args=None, callback=None, disable=None,
     s_in = x.new_ones([x.shape[0]])
     sh = _host_sigmas(sigmas, sigmas_host)
     fused = callback is None and not extra_args and getattr(model, "fused_step_ok", lambda _x: False)(x)
+    tables = None
     if fused:
         x = x.clone().contiguous()  # updated in place by the fused step
+        if STEP_TABLES and s_churn == 0. and len(sigmas) > 1:  # sigma_hat == sigma on every step: the wrapper's per-step scalars from one vectorised pass
+            c_in_all, t_all = model.eps_tables(sigmas[:-1])
+            t_rep = t_all.reshape(-1, 1).expand(-1, 2 * x.shape[0]).contiguous()
+            tables = (c_in_all, t_rep)
     for i in range(len(sigmas) - 1):
         gamma = min(s_churn / (len(sigmas) - 1), 2 ** 0.5 - 1) if s_tmin <= sh[i].item() <= s_tmax else 0.
         eps = torch.randn_like(x) * s_noise
@@ -230,7 +253,7 @@ def sample_euler(model, x, sigmas, extra_args=None, callback=None, disable=None,
             x = x + eps * ((sigma_hat ** 2 - sh[i] ** 2) ** 0.5).item()
         if fused:  # scalings + guidance + Euler update as one kernel (include/crg_hip.h: crg_cfg_euler_step)
             from . import ops
-            e2 = model.eps_pair(x, (sigmas[i] * (gamma + 1)) * s_in)
+            e2 = model.eps_pair_pre(x, tables[0][i], tables[1][i]) if tables is not None else model.eps_pair(x, (sigmas[i] * (gamma + 1)) * s_in)
             ops.cfg_euler_step_(x, e2.contiguous(), None, sigma_hat.item(), (sh[i + 1] - sigma_hat).item(), model.unconditional_guidance_scale)
             continue
         denoised = model(x, (sigmas[i] * (gamma + 1)) * s_in, **extra_args)
@@ -253,10 +276,14 @@ def sample_euler_ancestral(model, x, sigmas, extra_args=None, callback=None, dis
     fused = callback is None and not extra_args and getattr(model, "fused_step_ok", lambda _x: False)(x)
     if fused:
         x = x.clone().contiguous()  # updated in place by the fused step
+        tables = STEP_TABLES and len(sigmas) > 1
+        if tables:
+            c_in_all, t_all = model.eps_tables(sigmas[:-1])
+            t_rep = t_all.reshape(-1, 1).expand(-1, 2 * x.shape[0]).contiguous()
     for i in range(len(sigmas) - 1):
         if fused:  # scalings + guidance + Euler update + ancestral noise as one kernel (crg_cfg_euler_step)
             from . import ops
-            e2 = model.eps_pair(x, sigmas[i] * s_in)
+            e2 = model.eps_pair_pre(x, c_in_all[i], t_rep[i]) if tables else model.eps_pair(x, sigmas[i] * s_in)
             sigma_down, sigma_up = get_ancestral_step(sh[i], sh[i + 1], eta=eta)
             noise = noise_sampler(sigmas[i], sigmas[i + 1]).contiguous() if sh[i + 1].item() > 0 else None
             ops.cfg_euler_step_(x, e2.contiguous(), noise, sh[i].item(), (sigma_down - sh[i]).item(), model.unconditional_guidance_scale,
