@@ -1,10 +1,16 @@
-// 3x3 / stride 1 / pad 1 conv on 256-pixel tiles, PING-PONG schedule (gfx950).
+// 3x3 / stride 1 / pad 1 conv on 256-pixel tiles with the two waves of every SIMD out of step (gfx950).
 //
 // Same math, operand layout, LDS images and DMA pieces as conv3_ring_kernel (conv_ring.hip): tile = 256 output pixels x BN
 // output channels on 8 waves (4 x 2, each 64 x 16 WNT), K in (64-channel chunk, kernel row) groups of three k-tiles that share
 // one row buffer, weight k-tiles through a 4-slot ring, everything by buffer_load ... lds behind counted s_waitcnt vmcnt(n).
+// Three schedules (template parameter SCHED), bitwise equal in their results (tests/test_hip_ops.py::test_conv_schedules):
+//   SCHED 1 (the default, CRG_RING = 6): the STAGGER - one barrier per k-tile, waves 0-3 multiply k-tile t and then read k-tile t + 1
+//            while waves 4-7 read k-tile t and then multiply it; described in front of its code further down.  8 % faster than the ring kernel.
+//   SCHED 2 (CRG_RING = 7): the stagger with the DMA pieces threaded between the MFMA groups - 3 % slower than SCHED 1.
+//   SCHED 0 (CRG_RING = 5): the 4-barrier PING-PONG described next - built first, as fast as the ring kernel, no faster (a barrier hand-off
+//            idles the matrix pipe for ~180 cycles); kept for the record and for the schedule-equivalence test.
 //
-// What is different is WHEN the two waves of a SIMD do what.  In the ring kernel all eight waves run the same stream between
+// SCHED 0.  What is different is WHEN the two waves of a SIMD do what.  In the ring kernel all eight waves run the same stream between
 // the same barriers: both waves of a SIMD multiply together (and share the matrix pipe), then both read fragments and issue
 // their DMA pieces together (and the matrix pipe idles) - measured, the three costs ADD: 0.60 us of MFMAs + 0.25 us of LDS
 // reads + 0.19 us of DMA issue = the 1.0 - 1.1 us a k-tile takes.  Here a k-tile is two PHASES of
