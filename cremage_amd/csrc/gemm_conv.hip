@@ -1570,8 +1570,9 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     // fill the chip once more for a fraction of a round, and are summed by the split-K reduce over just their rows.
     const int T = p.tile_count, nk = (p.K + BK - 1) / BK;
     const int r = T % 512, T1 = T - r;
+    // (not with a transposed column range: the K-split tail would have to emit V^T from the reduce pass - ADVICE r3)
     if (cfg == 1 && p.rowhalo != 2 && p.splits == 1 && batch == 1 && T1 >= 512 && r > 0 && r <= 224 && nk >= 16 && r % p.tiles_n == 0 &&
-        p.epi != CRG_EPI_GEGLU && !(p.N & 3)) {
+        p.epi != CRG_EPI_GEGLU && !(p.N & 3) && !p.vt) {
       int s2 = 512 / r;
       if (s2 > nk / 4) s2 = nk / 4;
       if (s2 > 8) s2 = 8;

@@ -23,13 +23,14 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None) -> tuple:
+def init_from_env(backend: Optional[str] = None, force: bool = False) -> tuple:
     """(rank, world_size, local_rank) from the torchrun environment; initialises the default group when
-    WORLD_SIZE > 1 (rendezvous on MASTER_ADDR/MASTER_PORT)."""
+    WORLD_SIZE > 1 (rendezvous on MASTER_ADDR/MASTER_PORT).  `force`: initialise the group at world size 1 as well (a one-rank RCCL
+    communicator: tests/test_rccl_gpu.py proves the communicator, the dmabuf-IPC environment and the bucket code on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -58,9 +59,10 @@ def image_seed(seed: int, global_index: int) -> int:
 
 
 @torch.no_grad()
-def broadcast_parameters_(tensors: Iterable[torch.Tensor], src: int = 0, group=None) -> int:
-    """Broadcast all tensors from `src` as one flat buffer per (dtype, device); returns bytes sent."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def broadcast_parameters_(tensors: Iterable[torch.Tensor], src: int = 0, group=None, force: bool = False) -> int:
+    """Broadcast all tensors from `src` as one flat buffer per (dtype, device); returns bytes sent.  `force`: run the collectives on a
+    one-rank group too (otherwise a no-op there)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return 0
     buckets = {}
     for t in tensors:
@@ -93,14 +95,14 @@ def broadcast_parameters_(tensors: Iterable[torch.Tensor], src: int = 0, group=N
 
 
 @torch.no_grad()
-def broadcast_module_(module: torch.nn.Module, src: int = 0, group=None) -> int:
-    return broadcast_parameters_(list(module.parameters()) + list(module.buffers()), src=src, group=group)
+def broadcast_module_(module: torch.nn.Module, src: int = 0, group=None, force: bool = False) -> int:
+    return broadcast_parameters_(list(module.parameters()) + list(module.buffers()), src=src, group=group, force=force)
 
 
 @torch.no_grad()
-def all_gather_batch(x: torch.Tensor, group=None) -> torch.Tensor:
-    """[b, ...] per rank -> [world*b, ...] on every rank, rank-major (equal b on all ranks)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def all_gather_batch(x: torch.Tensor, group=None, force: bool = False) -> torch.Tensor:
+    """[b, ...] per rank -> [world*b, ...] on every rank, rank-major (equal b on all ranks).  `force`: as in broadcast_parameters_."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return x
     world = dist.get_world_size(group)
     x = x.contiguous()

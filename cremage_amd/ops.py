@@ -169,6 +169,16 @@ def _gn_stats_of(t: torch.Tensor, hw: int) -> Optional[torch.Tensor]:
     return g[0]
 
 
+def _written(t: torch.Tensor) -> torch.Tensor:
+    """A kernel of this library just wrote `t` in place through its raw pointer: tell PyTorch (bump `_version`), so that everything keyed
+    on the version - the GroupNorm statistics riding on the tensor (`_crg_gn`), the cross-attention K / V cache, the weight caches -
+    sees the write as it sees a torch in-place op.  A raw write through a VIEW bumps the shared counter of the base as well."""
+    torch.autograd.graph.increment_version(t)
+    if hasattr(t, "_crg_gn"):
+        del t._crg_gn
+    return t
+
+
 def f32_vec(v: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     """fp32 contiguous view/copy of a bias / norm gain (kernels take fp32 vectors)."""
     if v is None:
@@ -337,7 +347,7 @@ def softmax_rows_(x: torch.Tensor, cols: int, scale: float):
     rows = x.numel() // ld
     h = _h(x)
     L.check(L.load().crg_softmax_rows(h, _st(), _p(x), _p(x), rows, cols, ld, scale, _act_dt(x)), h, "crg_softmax_rows")
-    return x
+    return _written(x)
 
 
 # ---------------------------------------------------------------------------------- GEMM family
@@ -570,8 +580,8 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if cin <= 8 or (cout <= 8 and (cin % 8 != 0 or cin < 64)):
         if x_lo is not None:
             raise L.CrgError("conv2d: thin-channel convs take the fp32 tensor, not split planes")
-        if stride != 1 or upsample2x or x2 is not None or cvec is not None or residual is not None or (pt, pl, pb, pr) != (ks // 2,) * 4:
-            raise L.CrgError("conv2d: thin-channel convs support only stride 1, 'same' padding, no fusions")
+        if stride != 1 or upsample2x or x2 is not None or cvec is not None or residual is not None or gn is not None or (pt, pl, pb, pr) != (ks // 2,) * 4:
+            raise L.CrgError("conv2d: thin-channel convs support only stride 1, 'same' padding, no fusions (no fused GroupNorm either)")
         y = empty_image(n, cout, ho, wo, x.dtype, x.device)
         w32 = f32_vec(weight)
         h = _h(x)
@@ -765,7 +775,7 @@ def axpby_(y: torch.Tensor, x: torch.Tensor, a: float, b: float = 1.0) -> torch.
         raise L.CrgError("axpby_: operands must agree in shape, strides and dtype")
     h = _h(x)
     L.check(L.load().crg_axpby(h, _st(), _p(x), _p(y), x.numel(), a, b, _act_dt(x)), h, "crg_axpby")
-    return y
+    return _written(y)
 
 
 def cfg_euler_step_(x: torch.Tensor, eps2: torch.Tensor, noise: Optional[torch.Tensor], sigma: float, dt: float, cfg_scale: float,
@@ -779,7 +789,7 @@ def cfg_euler_step_(x: torch.Tensor, eps2: torch.Tensor, noise: Optional[torch.T
     h = _h(x)
     L.check(L.load().crg_cfg_euler_step(h, _st(), _p(x), _p(eps2), _p(noise), x.numel(), float(sigma), float(dt), float(cfg_scale),
                                         float(noise_scale)), h, "crg_cfg_euler_step")
-    return x
+    return _written(x)
 
 
 # ---------------------------------------------------------------------------------- profiling

@@ -177,6 +177,7 @@ class LDMWrapperForKDiffusion(nn.Module):
         CompVisDenoiser.forward (external.py:111-114) performs per step on the batch-expanded sigma, so the values are identical;
         computed once per sampling run they replace ~25 tiny launches per step (scalings, log / searchsorted / blend of sigma_to_t)."""
         cv = self.compviz_model
+        sigmas = sigmas.to(cv.log_sigmas.device)  # a CPU schedule worked with the per-step scalars (0-dim broadcast); keep it working
         _, c_in = cv.get_scalings(sigmas)
         return c_in, cv.sigma_to_t(sigmas)
 

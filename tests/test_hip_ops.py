@@ -74,7 +74,10 @@ def test_linear_shapes(dtype, M, N, K):
     check(got2, ref2, dtype, "linear+silu")
 
 
-@pytest.mark.parametrize("B,T,K,C", [(8, 1024, 640, 640), (2, 256, 1280, 1280), (3, 1000, 320, 320), (4, 4096, 640, 640), (2, 64, 1280, 1280)])
+@pytest.mark.parametrize("B,T,K,C", [(8, 1024, 640, 640), (2, 256, 1280, 1280), (3, 1000, 320, 320), (4, 4096, 640, 640), (2, 64, 1280, 1280),
+                                     # 65 x 24 = 1560 tiles = 3 x 512 + 24: the grid shape whose last 24 tiles used to go out as a K-split tail
+                                     # launch, which cannot emit the transposed range (CrgError -22 mid-call)
+                                     (10, 832, 1280, 1280)])
 def test_linear_transposed_range(B, T, K, C):
     """crg_gemm with a transposed column range (the V third of a fused Q | K | V projection written as V^T [B][C][roundup(T, 8)] by the
     GEMM's own epilogue) on the three tile configurations (A / C / D), a token count that is no multiple of 8, and a K = 320 input
@@ -773,6 +776,42 @@ def test_flash_attention_lds_dma_form(heads, d, Nq, Nk):
     got = ops.attention(dq, dk, vt, heads, Nk, d ** -0.5).float().cpu()
     rel = ((got - ref).norm() / ref.norm()).item()
     assert torch.isfinite(got).all() and rel < 1e-2, (rel, heads, d, Nq, Nk)
+
+
+@pytest.mark.parametrize("heads,d,Nq,Nk", [(8, 40, 2100, 77), (8, 40, 2048, 4), (8, 64, 2100, 64), (8, 64, 2050, 128), (8, 80, 2100, 81),
+                                           (8, 160, 2064, 77), (16, 8, 1100, 5), (8, 48, 2100, 100), (8, 128, 2100, 96)])
+@pytest.mark.parametrize("row_major_v", [False, True])
+def test_flash_attention_few_keys_kernel(heads, d, Nq, Nk, row_major_v):
+    """attn_ctx_kernel (Nk <= 128 and ceil(Nq / 128) * B * H >= 2048 blocks' worth of query groups: the 64x64-level cross-attention
+    against the prompt context, FaceID's 4 tokens): both key tiles staged once per block, the block then walks several 128-query groups
+    with the next group's Q fragments requested ahead.  B = 16 reaches the dispatch threshold; one and two key tiles, key tails (77, 81,
+    4, 5, 100), a query tail in the last group, every head-dim family (k-steps 1, 3, 4, 5, 8, 10 incl. the all-ones denominator variants),
+    transposed V (crg_attention, NaN pad columns) and row-major V (crg_attention_v: k / v column slices of one NaN-guarded buffer)."""
+    from cremage_amd import ops
+    B = 16
+    assert (Nq + 127) // 128 * B * heads >= 2048 and Nk <= 128  # the dispatch rule of attention_entry (attention.hip)
+    C = heads * d
+    qq, kk, vv = rnd(B, Nq, C, seed=470), rnd(B, Nk, C, seed=471), rnd(B, Nk, C, seed=472)
+    kk[3, Nk - 1] = qq[3, 7, :].clone() * 3.0  # a dominant last key (inside the tail tile)
+    ref = attn_ref(q(qq, BF), q(kk, BF), q(vv, BF), heads, d ** -0.5)
+    wide_q = torch.full((B, Nq, C + 16), float("nan"))
+    wide_q[..., 8:8 + C] = qq
+    dq = wide_q.to(_dev()).to(BF)[..., 8:8 + C]
+    if row_major_v:
+        kv = torch.full((B, Nk, 2 * C + 24), float("nan"))
+        kv[..., 8:8 + C] = kk
+        kv[..., 16 + C:16 + 2 * C] = vv
+        kv = kv.to(_dev()).to(BF)
+        got = ops.attention_rows_v(dq, kv[..., 8:8 + C], kv[..., 16 + C:16 + 2 * C], heads, d ** -0.5)
+    else:
+        ld = (Nk + 7) // 8 * 8
+        vt = torch.full((B, C, ld), float("nan"))
+        vt[:, :, :Nk] = vv.transpose(1, 2)
+        got = ops.attention(dq, kk.to(_dev()).to(BF), vt.to(_dev()).to(BF), heads, Nk, d ** -0.5)
+    got = got.float().cpu()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    worst = ((got - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)).max().item()  # per sample: a wrong group cannot hide in the norm
+    assert torch.isfinite(got).all() and rel < 1e-2 and worst < 1.5e-2, (rel, worst, heads, d, Nq, Nk)
 
 
 @pytest.mark.parametrize("gain", [30.0, 300.0])
