@@ -42,6 +42,8 @@ class GemmArgs(C.Structure):
         ("a_lo", c_void_p),
         ("gn_stats", c_void_p),
         ("vt", c_void_p), ("vt_n0", c_int), ("vt_tokens", c_int), ("vt_ld", c_int64),
+        ("row_stats", c_void_p), ("row_stats_parts", c_int),
+        ("ln_stats", c_void_p), ("ln_parts", c_int), ("ln_colsum", c_void_p), ("ln_eps", c_float),
     ]
 
 
@@ -109,6 +111,7 @@ SIGNATURES = {
     "crg_ln_gemm": (c_int, [c_void_p, c_void_p, C.POINTER(LnGemmArgs)]),
     "crg_pack_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "crg_pack_geglu_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "crg_pack_ln_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "crg_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                               c_int, c_int, c_int, c_int, c_int, c_float, c_int]),
     "crg_attention_v": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
@@ -147,8 +150,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.crg_version() != 101:
-        raise CrgError(f"libcrg_hip.so version {lib.crg_version()} does not match the binding (101)")
+    if lib.crg_version() != 102:
+        raise CrgError(f"libcrg_hip.so version {lib.crg_version()} does not match the binding (102)")
     if lib.crg_half_kind() != (1 if HALF_F16 else 0):
         raise CrgError(f"{LIB_PATH} computes in {'fp16' if lib.crg_half_kind() else 'bf16'} but CRG_HALF asks for {'fp16' if HALF_F16 else 'bf16'}")
     _lib = lib

@@ -41,14 +41,10 @@ def _as_act(t: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
 class ControlledUnetModel(UNetModel):
     """cldm.py:28-70.  With control=None it is the plain UNetModel (:57, :60-61)."""
 
-    def forward(self, x, timesteps=None, context=None, control=None, only_mid_control=False, **kwargs):
+    def forward(self, x, timesteps=None, context=None, control=None, only_mid_control=False, cfg_dup: bool = False, **kwargs):
         cdt, emb, context = self._prologue(timesteps, context)
         control = list(control) if control is not None else None
-        hs = []
-        h = ops.nchw_to_nhwc(x, cdt)
-        for module in self.input_blocks:
-            h = module(h, emb, context)
-            hs.append(h)
+        h, hs = self._input_blocks(x, cdt, emb, context, cfg_dup or getattr(x, "_crg_cfg_dup", False))  # the encoder runs no_grad / unchanged (:47-56)
         h = self.middle_block(h, emb, context)
         if control is not None:
             h = h.add_(_as_act(control.pop(), h))                      # Change 1 (:57-58)

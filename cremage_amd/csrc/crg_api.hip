@@ -182,7 +182,63 @@ __global__ void pack_geglu_bias_kernel(const float* __restrict__ src, float* __r
   dst[o] = src[q * 16 + (r & 15) + (r >> 4) * F];
 }
 
+// one block per packed row o: dst_w = half(W * gamma), colsum over the rounded values, bias' = W beta + bias (fixed-order block reduce)
+template <typename ST>
+__global__ __launch_bounds__(256) void pack_ln_kernel(const ST* __restrict__ src, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ bias, int kind, int n_out, int n_in, bf16* __restrict__ dw,
+                                                      float* __restrict__ ds, float* __restrict__ db) {
+  __shared__ float red[2][4];
+  const int o = blockIdx.x, t = threadIdx.x;
+  int srow = o;
+  if (kind == CRG_PACK_GEGLU) {
+    const int F = n_out / 2, q = o >> 5, r = o & 31;
+    srow = q * 16 + (r & 15) + (r >> 4) * F;
+  }
+  const ST* w = src + (long)srow * n_in;
+  float s = 0.f, b = 0.f;
+  for (int k = t; k < n_in; k += 256) {
+    const float f = (float)w[k];
+    const bf16 h = (bf16)(f * gamma[k]);
+    dw[(long)o * n_in + k] = h;
+    s += (float)h;
+    b = __builtin_fmaf(f, beta[k], b);
+  }
+#pragma unroll
+  for (int x = 32; x > 0; x >>= 1) {
+    s += __shfl_xor(s, x);
+    b += __shfl_xor(b, x);
+  }
+  if ((t & 63) == 0) {
+    red[0][t >> 6] = s;
+    red[1][t >> 6] = b;
+  }
+  __syncthreads();
+  if (t == 0) {
+    ds[o] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    db[o] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]) + (bias ? bias[srow] : 0.f);
+  }
+}
+
 }  // namespace
+
+extern "C" int crg_pack_ln_weight(crg_ctx* ctx, void* stream, const void* src, int src_dtype, const float* gamma, const float* beta,
+                                  const float* bias, int kind, int n_out, int n_in, void* dst_w, float* dst_colsum, float* dst_bias) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, src && gamma && beta && dst_w && dst_colsum && dst_bias && n_out > 0 && n_in > 0, "pack_ln_weight: bad arguments");
+  CRG_REQUIRE(ctx, kind == CRG_PACK_LINEAR || kind == CRG_PACK_GEGLU, "pack_ln_weight: kind %d unsupported", kind);
+  if (kind == CRG_PACK_GEGLU) CRG_REQUIRE(ctx, n_out % 32 == 0, "pack_ln_weight: GEGLU needs n_out %% 32 == 0, got %d", n_out);
+  hipStream_t st = (hipStream_t)stream;
+  if (src_dtype == CRG_F32)
+    hipLaunchKernelGGL(pack_ln_kernel<float>, dim3(n_out), dim3(256), 0, st, (const float*)src, gamma, beta, bias, kind, n_out, n_in, (bf16*)dst_w, dst_colsum, dst_bias);
+  else if (src_dtype == CRG_BF16)
+    hipLaunchKernelGGL(pack_ln_kernel<bf16>, dim3(n_out), dim3(256), 0, st, (const bf16*)src, gamma, beta, bias, kind, n_out, n_in, (bf16*)dst_w, dst_colsum, dst_bias);
+  else if (src_dtype == CRG_F16)
+    hipLaunchKernelGGL(pack_ln_kernel<_Float16>, dim3(n_out), dim3(256), 0, st, (const _Float16*)src, gamma, beta, bias, kind, n_out, n_in, (bf16*)dst_w, dst_colsum, dst_bias);
+  else
+    return crg_fail(ctx, -22, "pack_ln_weight: unsupported source dtype %d", src_dtype);
+  CRG_CHECK_LAUNCH(ctx, "pack_ln_weight");
+  return 0;
+}
 
 extern "C" int crg_pack_weight(crg_ctx* ctx, void* stream, const void* src, int src_dtype, int kind, int n_out, int n_in,
                                int ksize, void* dst_hi, void* dst_lo) {

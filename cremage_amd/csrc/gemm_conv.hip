@@ -291,14 +291,19 @@ __device__ __forceinline__ void wait_batches(int n) {
 
 // (launch bounds: configuration A - 128-row tiles, 4 waves, 2 stages - is built for TWO blocks per CU: its register budget is 256.  The
 // plain instantiations fit it on their own (156 VGPRs + 80 accumulators); the one that emits GroupNorm statistics needs the cap.)
-template <int WNT, typename YT, bool CONV, int STAGES, int WMT, int KG, int NS = 1, bool PAIR = false, bool GST = false>
+// XT: the extra side channel this instantiation carries (each keeps ~10-40 more values live, hence template arms rather than runtime branches):
+//   0 none; 1 = GST, emits GroupNorm statistics (p.gstat); 2 = RST, emits LayerNorm row statistics (p.rstat); 3 = LNE, LayerNorm as an
+//   epilogue correction from the producer's row statistics (p.ln_stat, see GemmP) - no residual in that form (none of its callers has one)
+template <int WNT, typename YT, bool CONV, int STAGES, int WMT, int KG, int NS = 1, bool PAIR = false, int XT = 0>
 #ifndef CRG_LB_A  // dev knob (tools/build_variant.sh): 1 (default) = every configuration-A instantiation is capped at 256 registers (unified file: 191-204
            // VGPRs, no accumulator registers; bench A/B in one call: 246.6 -> 245.6 ms), 0 = only the statistics one
 #define CRG_LB_A 1
 #endif
-__global__ __launch_bounds__(256 * KG, ((GST || CRG_LB_A) && KG == 1 && WMT == 4 && STAGES == 2 && NS == 1) ? 2 : 1) void gemm_glds_kernel(GemmP p) {
+__global__ __launch_bounds__(256 * KG, ((XT != 0 || CRG_LB_A) && KG == 1 && WMT == 4 && STAGES == 2 && NS == 1) ? 2 : 1) void gemm_glds_kernel(GemmP p) {
+  constexpr bool GST = XT == 1, RST = XT == 2, LNE = XT == 3;
   static_assert(!PAIR || (sizeof(YT) == 2 && NS == 1), "paired columns: bf16 output, single-plane operands");
-  static_assert(!GST || PAIR, "GroupNorm statistics come from the paired epilogue");  // GST: the instantiation that emits them (p.gstat set)
+  static_assert(!(GST || RST) || PAIR, "GroupNorm / LayerNorm statistics come from the paired epilogue");  // GST / RST: the instantiations that emit them
+  static_assert(!LNE || (!CONV && NS == 1 && sizeof(YT) == 2), "LayerNorm epilogue: bf16 GEMM");
   // NS = 2: split-bf16 (fp32-class) operands - the activations arrive pre-split as two bf16 planes (hi = bf16(x),
   // lo = bf16(x - hi), written by the producing GroupNorm / split pass), the weights as their two packed planes; all four
   // are staged by LDS-DMA and every fragment pair costs three MFMAs (hi*hi + hi*lo + lo*hi).
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(256 * KG, ((GST || CRG_LB_A) && KG == 1 && WMT == 4
   bf16x8 r2[PAIR ? (WNT / 2 > 0 ? WNT / 2 : 1) : 1][PAIR ? WMT : 1];
   bf16x4 r1[PAIR ? WMT : 1];
   f32x4 bpre[WNT];
-  const bool pre_res = sizeof(YT) == 2 && p.res && p.splits == 1 && (p.ldr & 3) == 0 && (p.N & 3) == 0 && p.epi != CRG_EPI_GEGLU;
+  const bool pre_res = !LNE && sizeof(YT) == 2 && p.res && p.splits == 1 && (p.ldr & 3) == 0 && (p.N & 3) == 0 && p.epi != CRG_EPI_GEGLU;
   const bool pre_bias = p.bias_mode == CRG_BIAS_COL && p.splits == 1 && (p.N & 3) == 0 && p.epi != CRG_EPI_GEGLU;
   if (kg == 0) {
     const int nb = n0 + wn * (16 * WNT);
@@ -526,6 +531,30 @@ __global__ __launch_bounds__(256 * KG, ((GST || CRG_LB_A) && KG == 1 && WMT == 4
 #pragma unroll
   for (int s = 0; s < D; ++s)
     if (kt_begin + s < nk) stage(s);
+  // LNE: (rstd, mean * rstd) of this lane's rows and the column sums ln_s of its columns.  Lane l of the wave folds the partials of the
+  // wave's row l (coalesced: consecutive lanes, consecutive rows of a plane); the values of rows 16 j + frow come over by ds_bpermute.
+  // Placed BEHIND the first DMA batches: the fold needs the partials, so the wait it implies covers the DMA latency it runs beside
+  // (ahead of them it would put a load round trip in front of every block's first DMA).
+  float ln_a = 0.f, ln_b = 0.f;
+  f32x4 spre[LNE ? WNT : 1];
+  if constexpr (LNE) {
+    if (kg == 0) {
+      const int rl = lane < 16 * WMT ? lane : 16 * WMT - 1;
+      const int mr = m0 + wm * (16 * WMT) + rl;
+      const float* q = p.ln_stat + (mr < p.M ? mr : p.M - 1);
+      const long plane = (long)p.ln_parts * p.M;
+      for (int u = 0; u < p.ln_parts; ++u) {
+        ln_a += q[(long)u * p.M];
+        ln_b += q[plane + (long)u * p.M];
+      }
+      const int nb = n0 + wn * (16 * WNT);
+#pragma unroll
+      for (int i = 0; i < WNT; ++i) {
+        const int n = (PAIR && i < 2 * (WNT / 2)) ? nb + 32 * (i >> 1) + 8 * fq + 4 * (i & 1) : nb + 16 * i + 4 * fq;
+        spre[i] = *reinterpret_cast<const f32x4*>(p.ln_s + (n + 4 <= p.N ? n : p.N - 4));
+      }
+    }
+  }
 
   int buf = 0, nbuf = D;  // ring positions of tile kt and of tile kt + D
   // PF (the one-block-per-CU in-block split-K configuration: 64-row tiles, 8 waves, 4 stages): the fragments of k-tile kt + 1 are
@@ -660,7 +689,22 @@ __global__ __launch_bounds__(256 * KG, ((GST || CRG_LB_A) && KG == 1 && WMT == 4
 #pragma unroll
       for (int j = 0; j < WMT; ++j) acc[i][j] += red[(i * WMT + j) * 64];
   }
-  if constexpr (PAIR && !CONV && !GST) {
+  if constexpr (LNE) {
+    // y = rstd * (acc - mean * s[n]) (+ bias' in the epilogue): LayerNorm(x) W^T from the GEMM on the raw rows
+    const float invk = 1.0f / (float)p.K;
+    const float mean = ln_a * invk;
+    float var = __builtin_fmaf(-mean, mean, ln_b * invk);
+    var = var > 0.f ? var : 0.f;
+    const float rstd = __builtin_amdgcn_rsqf(var + p.ln_eps);
+    const float mrs = mean * rstd;
+#pragma unroll
+    for (int j = 0; j < WMT; ++j) {
+      const float rj = __shfl(rstd, j * 16 + frow), mj = __shfl(mrs, j * 16 + frow);
+#pragma unroll
+      for (int i = 0; i < WNT; ++i) acc[i][j] = rj * acc[i][j] - mj * spre[i];
+    }
+  }
+  if constexpr (PAIR && !CONV && !GST && !RST) {
     if (p.vt && n0 >= p.vt_n0) {
       // transposed n-tile (the V third of a fused Q | K | V projection -> V^T [sample][channel][token], what the LDS-DMA / pipelined
       // attention kernels stage): lane = one token x 8 (4) consecutive channels -> one 2-byte store per channel; the 16 lanes of a
@@ -700,7 +744,7 @@ __global__ __launch_bounds__(256 * KG, ((GST || CRG_LB_A) && KG == 1 && WMT == 4
     }
   }
   if constexpr (PAIR) {
-    gemm_epilogue_pairs<WNT, WMT, GST ? 1 : 0>(p, acc, m0, n0, wm, wn, frow, fq, bz, r2, r1, pre_res, bpre, pre_bias);
+    gemm_epilogue_pairs<WNT, WMT, GST ? 1 : 0, RST>(p, acc, m0, n0, wm, wn, frow, fq, bz, r2, r1, pre_res, bpre, pre_bias);
   } else {
     gemm_epilogue<WNT, YT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, bz, sid, rres, pre_res, bpre, pre_bias);
   }
@@ -1202,6 +1246,52 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmP p) {
   }
 }
 
+// Split-K second pass that ALSO emits the LayerNorm row statistics (GemmP::rstat) of the finished rows: a wave owns a row at a time (lanes
+// stride over its 4-column groups), sums the rounded outputs and their squares, folds the 64 lanes with shuffles (fixed order) and writes
+// the whole-row sums into partial 0; the other partials of the row are zeroed (the consumer folds all rstat_parts of them).
+__global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(GemmP p) {
+  const int n4 = p.N >> 2;
+  const long srows = p.M - p.slab_row0;
+  const float* S = p.slab - (long)p.slab_row0 * p.N;
+  bf16* Y = reinterpret_cast<bf16*>(p.y);
+  const bf16* R = reinterpret_cast<const bf16*>(p.res);
+  const int lane = threadIdx.x & 63;
+  const long plane = (long)p.rstat_parts * p.M;
+  for (int m = p.slab_row0 + blockIdx.x * 4 + (threadIdx.x >> 6); m < p.M; m += gridDim.x * 4) {
+    float q1 = 0.f, q2 = 0.f;
+    for (int c = lane; c < n4; c += 64) {
+      const int n = c * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(S + (long)m * p.N + n);
+      for (int s = 1; s < p.splits; ++s) v += *reinterpret_cast<const f32x4*>(S + ((long)s * srows + m) * p.N + n);
+      if (p.bias_mode == CRG_BIAS_COL) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      else if (p.bias_mode == CRG_BIAS_ROW) v += p.bias[m];
+      if (R) {
+        const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(R + (long)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+      }
+      bf16x4 o4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o4[e] = (bf16)v[e];
+        const float f = (float)o4[e];
+        q1 += f;
+        q2 = __builtin_fmaf(f, f, q2);
+      }
+      *reinterpret_cast<bf16x4*>(Y + (long)m * p.ldy + n) = o4;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      q1 += __shfl_xor(q1, o);
+      q2 += __shfl_xor(q2, o);
+    }
+    if (lane < p.rstat_parts) {
+      p.rstat[(long)lane * p.M + m] = lane == 0 ? q1 : 0.f;
+      p.rstat[plane + (long)lane * p.M + m] = lane == 0 ? q2 : 0.f;
+    }
+  }
+}
+
 // Split-K second pass FUSED with the GroupNorm(+SiLU) that consumes the conv's output (openaimodel.py:208 -> :229-231 inside a ResBlock),
 // for the small images of the two lowest UNet levels: one block per (sample, group) sums the K slices of its HW x gs slab in slice order,
 // adds bias / per-sample vector / residual in the order of splitk_reduce_kernel, rounds to bf16 and stores the raw output, and then
@@ -1346,7 +1436,12 @@ int launch_reduce(crg_ctx* ctx, hipStream_t st, const GemmP& p, int batch) {
     ctx->gn_fused = true;
     return 0;
   }
-  if (p.gstat) {
+  if (p.rstat) {
+    if (sizeof(YT) != 2 || batch != 1 || (p.N & 3) || (p.ldy & 3) || p.epi != CRG_EPI_NONE || p.cvec || p.rstat_parts > 64 || (p.res && (p.ldr & 3)))
+      return crg_fail(ctx, -22, "gemm: LayerNorm row statistics behind split-K need an unbatched plain bf16 problem with 4-aligned N / ldy / ldr");
+    const long blocks = (rows + 3) / 4;
+    hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, p);
+  } else if (p.gstat) {
     if (batch != 1 || (p.N & 3) || (p.ldy & 3) || (p.slab_row0 & 31) || (p.res && (p.ldr & 3)))
       return crg_fail(ctx, -22, "gemm: GroupNorm statistics need an unbatched problem with 4-aligned N / ldy / ldr");
     hipLaunchKernelGGL(splitk_reduce_stats_kernel<YT>, dim3((unsigned)((rows + 31) / 32), (unsigned)((p.N + 127) / 128)), dim3(256), 0, st, p);
@@ -1363,7 +1458,7 @@ int launch_reduce(crg_ctx* ctx, hipStream_t st, const GemmP& p, int batch) {
 // than 2 blocks per CU and stream long K; cut K so that ~512 blocks are in flight, keeping >= 8 k-tiles
 // per slice.  Costs one fp32 slab round trip + one extra launch, so only when the tile count is low.
 inline int choose_splits(const GemmP& p, int tiles, int batch) {
-  if (p.epi == CRG_EPI_GEGLU || (p.N & 3)) return 1;
+  if (p.epi == CRG_EPI_GEGLU || (p.N & 3) || p.ln_stat) return 1;  // (the LayerNorm correction is per whole row sum: no K slices)
   const int nk = (p.K + BK - 1) / BK;
   const long blocks = (long)tiles * batch;
   // 256..511 blocks leave one block (4 waves) on most CUs, which hides neither the barrier nor the DMA latency: cut K in
@@ -1439,9 +1534,21 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     return crg_fail(ctx, -22, "gemm: a transposed column range needs the paired bf16 epilogue of an unsplit, unbatched GEMM (N, ldy multiples of 8, K below the split-K rule)");
   if (p.gstat && !p.pair && (p.splits == 1 || p.inred))
     return crg_fail(ctx, -22, "gemm/conv: GroupNorm statistics come from the paired bf16 epilogue (N, ldy, ldr multiples of 8, 16-byte aligned y / residual, no GEGLU)");
+  if (p.rstat && !(!p.gstat && !p.vt && !CONV && batch == 1 && sizeof(YT) == 2 && p.rstat_parts == 2 * p.tiles_n && p.epi == CRG_EPI_NONE &&
+                   ((p.splits == 1 && p.pair) || (p.splits > 1 && !p.inred && (p.N & 3) == 0 && (p.ldy & 3) == 0 && (!p.res || (p.ldr & 3) == 0)))))
+    return crg_fail(ctx, -22, "gemm: LayerNorm row statistics come from the paired bf16 epilogue of an unbatched plain GEMM (N, ldy multiples of 8) or from its split-K reduce, with row_stats_parts = 2 * ceil(N / tile) = %d (got %d)", 2 * p.tiles_n, p.rstat_parts);
+  if (p.ln_stat && !(GLDS && sizeof(YT) == 2 && !CONV && p.splits == 1 && batch == 1 && !p.res && !p.gstat && !p.rstat && !p.cvec && (p.N & 3) == 0 &&
+                     (p.bias_mode == CRG_BIAS_COL || p.bias_mode == CRG_BIAS_NONE) && (p.epi == CRG_EPI_NONE || p.epi == CRG_EPI_GEGLU)))
+    return crg_fail(ctx, -22, "gemm: the LayerNorm epilogue needs an unsplit, unbatched bf16 GEMM (N %% 4 == 0) without residual / statistics / SiLU");
   void (*kern)(GemmP);
-  if constexpr (GLDS && sizeof(YT) == 2)
-    kern = p.pair ? ((p.gstat && p.splits == 1) ? gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG, 1, true, true> : gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG, 1, true>)
+  if constexpr (GLDS && sizeof(YT) == 2 && !CONV) {
+    if (p.ln_stat) kern = p.pair ? gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG, 1, true, 3> : gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG, 1, false, 3>;
+    else if (p.rstat && p.splits == 1) kern = gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG, 1, true, 2>;
+    else
+      kern = p.pair ? ((p.gstat && p.splits == 1) ? gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG, 1, true, 1> : gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG, 1, true>)
+                    : gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG>;
+  } else if constexpr (GLDS && sizeof(YT) == 2)
+    kern = p.pair ? ((p.gstat && p.splits == 1) ? gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG, 1, true, 1> : gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG, 1, true>)
                   : gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG>;
   else if constexpr (GLDS) kern = gemm_glds_kernel<WNT, YT, CONV, STAGES, WMT, KG>;
   else kern = gemm_kernel<WNT, NSPLIT, AT, YT, CONV, NSPLIT>;  // split-bf16: 8 waves (two k-groups)
@@ -1572,7 +1679,7 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     const int r = T % 512, T1 = T - r;
     // (not with a transposed column range: the K-split tail would have to emit V^T from the reduce pass - ADVICE r3)
     if (cfg == 1 && p.rowhalo != 2 && p.splits == 1 && batch == 1 && T1 >= 512 && r > 0 && r <= 224 && nk >= 16 && r % p.tiles_n == 0 &&
-        p.epi != CRG_EPI_GEGLU && !(p.N & 3) && !p.vt) {
+        p.epi != CRG_EPI_GEGLU && !(p.N & 3) && !p.vt && !p.rstat && !p.ln_stat) {
       int s2 = 512 / r;
       if (s2 > nk / 4) s2 = nk / 4;
       if (s2 > 8) s2 = 8;
@@ -1734,6 +1841,21 @@ extern "C" int crg_gemm(crg_ctx* ctx, void* stream, const crg_gemm_args* a) {
                          ((uintptr_t)a->vt & 1) == 0,
                 "gemm: transposed range n0=%d (tile %d) tokens=%d ld=%ld inconsistent with M=%d N=%d", a->vt_n0, bn_, a->vt_tokens, (long)a->vt_ld, a->M, a->N);
     p.vt = (bf16*)a->vt; p.vt_n0 = a->vt_n0; p.vt_T = a->vt_tokens; p.vt_ld = a->vt_ld;
+  }
+  if (a->row_stats) {
+    CRG_REQUIRE(ctx, a->prec == CRG_PREC_BF16 && a->a_dtype == CRG_BF16 && a->y_dtype == CRG_BF16 && a->batch == 1 && a->epilogue == CRG_EPI_NONE &&
+                         !a->gn_stats && !a->vt && !a->ln_stats && (a->N & 7) == 0 && a->row_stats_parts > 0 && ((uintptr_t)a->row_stats & 3) == 0,
+                "gemm: row_stats need a plain unbatched bf16 GEMM with N %% 8 == 0 (no GroupNorm statistics / transposed range / LayerNorm epilogue)");
+    p.rstat = a->row_stats; p.rstat_parts = a->row_stats_parts;
+  }
+  if (a->ln_stats) {
+    CRG_REQUIRE(ctx, a->prec == CRG_PREC_BF16 && a->a_dtype == CRG_BF16 && a->y_dtype == CRG_BF16 && a->batch == 1 && !a->residual && !a->gn_stats &&
+                         (a->epilogue == CRG_EPI_NONE || a->epilogue == CRG_EPI_GEGLU) && (a->bias_mode == CRG_BIAS_COL || !a->bias) && (a->N & 3) == 0,
+                "gemm: the LayerNorm epilogue needs an unbatched bf16 GEMM, N %% 4 == 0, epilogue NONE / GEGLU, no residual / row bias / statistics");
+    CRG_REQUIRE(ctx, a->ln_colsum && a->ln_parts > 0 && a->ln_parts <= 64 && a->ln_eps >= 0.f && (((uintptr_t)a->ln_colsum | (uintptr_t)a->ln_stats) & 15) == 0 &&
+                         (a->M & 3) == 0,
+                "gemm: ln_stats needs ln_colsum, 1..64 partials per row, 16-byte aligned pointers and M %% 4 == 0");
+    p.ln_stat = a->ln_stats; p.ln_parts = a->ln_parts; p.ln_s = a->ln_colsum; p.ln_eps = a->ln_eps;
   }
   const double flops = 2.0 * a->M * (double)a->N * a->K * a->batch;
   const double bytes = ((double)a->M * a->K * crg_dtype_size(a->a_dtype) + (double)a->N * a->K * 2 +

@@ -112,6 +112,8 @@ struct RingP {
   int M, N, K, nk;
   int tiles_m, tiles_n, tile_count;
   int xg_m, xg_n;                              // XCD partition of the (m-tile, n-tile) grid (product 8) or 0: contiguous runs
+  // LayerNorm as an epilogue correction (GemmP::ln_stat): y = rstd_m * (acc - mean_m * ln_s[n]) + bias'[n] on the raw rows
+  const float* ln_stat; int ln_parts; const float* ln_s; float ln_eps;
 };
 
 // linear tile id -> (tile_m, tile_n): ids that are equal mod 8 run on one XCD (blocks are dealt round-robin and a block's ids are
@@ -138,7 +140,11 @@ static __device__ __forceinline__ void rg_tile(const RingP& p, int L, int& tile_
 // (bias, GELU, stores: as many vector-ALU cycles as the tile's MFMAs for GEGLU) to behind the next barrier, where it runs beside the
 // partner's MFMAs instead of beside the partner's epilogue (MI355X_MICROARCH.md "Two waves per SIMD" item 9).  Same ring, same slots,
 // same results bit for bit.
-template <int WNT, bool GEGLU, bool STAG = true>
+// LNE: the A rows are RAW LayerNorm inputs, W is W o gamma; every tile's epilogue folds the producer's row-statistics partials of its
+// 256 rows (lane l of a wave: row l of the wave's 64, coalesced; the rows a lane owns come over by ds_bpermute) and corrects the
+// accumulators before bias / GELU.  The loads sit in the epilogue like the bias loads (complete before the tile's stores go out, so the
+// counted waits see the same number of instructions in flight).
+template <int WNT, bool GEGLU, bool STAG = true, bool LNE = false>
 __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(RingP p) {
   constexpr bool PAIR = !GEGLU;
   constexpr int WMT = 4, NW = 8, TM = 256, NSLOT = 3;
@@ -250,6 +256,36 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(RingP p) {
     rg_tile(p, (int)blockIdx.x + i * G, tile_m, tile_n);
     const int m0 = tile_m * TM, n0 = tile_n * BN;
     const int nb = n0 + wn * (16 * WNT);
+    float rj[LNE ? WMT : 1], mj[LNE ? WMT : 1];
+    if constexpr (LNE) {
+      const int mr = m0 + wm * 64 + lane;
+      const float* q = p.ln_stat + (mr < p.M ? mr : p.M - 1);
+      const long plane = (long)p.ln_parts * p.M;
+      float a = 0.f, b = 0.f;
+      for (int u = 0; u < p.ln_parts; ++u) {
+        a += q[(long)u * p.M];
+        b += q[plane + (long)u * p.M];
+      }
+      const float invk = 1.0f / (float)p.K;
+      const float mean = a * invk;
+      float var = __builtin_fmaf(-mean, mean, b * invk);
+      var = var > 0.f ? var : 0.f;
+      const float rstd = __builtin_amdgcn_rsqf(var + p.ln_eps);
+      const float mrs = mean * rstd;
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) {
+        rj[j] = __shfl(rstd, j * 16 + frow);
+        mj[j] = __shfl(mrs, j * 16 + frow);
+      }
+    }
+    auto lncorr = [&](const f32x4& a4, int j, const f32x4& s4) -> f32x4 {
+      if constexpr (LNE) return rj[j] * a4 - mj[j] * s4;
+      else return a4;
+    };
+    auto lns = [&](int col, bool ok) -> f32x4 {
+      if constexpr (LNE) return *reinterpret_cast<const f32x4*>(p.ln_s + (ok ? col : 0));
+      else return f32x4{0.f, 0.f, 0.f, 0.f};
+    };
     if constexpr (GEGLU) {
 #pragma unroll
       for (int u2 = 0; u2 < WNT / 2; ++u2) {
@@ -262,10 +298,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(RingP p) {
           bv = *reinterpret_cast<const f32x4*>(p.bias + pc);
           bg = *reinterpret_cast<const f32x4*>(p.bias + pc + 16);
         }
+        const f32x4 sv = lns(pn, nok), sg = lns(pn + 16, nok);
 #pragma unroll
         for (int j = 0; j < WMT; ++j) {
           const int m = m0 + wm * 64 + j * 16 + frow;
-          const f32x4 v = acc[2 * u2][j] + bv, g = acc[2 * u2 + 1][j] + bg;
+          const f32x4 v = lncorr(acc[2 * u2][j], j, sv) + bv, g = lncorr(acc[2 * u2 + 1][j], j, sg) + bg;
           bf16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[e] * crg_gelu_erf_f(g[e]));
@@ -283,10 +320,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(RingP p) {
           ba = *reinterpret_cast<const f32x4*>(p.bias + pc);
           bb = *reinterpret_cast<const f32x4*>(p.bias + pc + 4);
         }
+        const f32x4 sa = lns(n, nok), sb = lns(n + 4, nok);
 #pragma unroll
         for (int j = 0; j < WMT; ++j) {
           const int m = m0 + wm * 64 + j * 16 + frow;
-          f32x4 a4 = acc[2 * u2][j] + ba, b4 = acc[2 * u2 + 1][j] + bb;
+          f32x4 a4 = lncorr(acc[2 * u2][j], j, sa) + ba, b4 = lncorr(acc[2 * u2 + 1][j], j, sb) + bb;
           if (p.res) {
             const bf16x8 r8 = rg_load16(p.res, p.res_bytes, (nok && m < p.M) ? (int)(((long)m * p.ldr + n) * 2) : OOB);
 #pragma unroll
@@ -309,10 +347,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(RingP p) {
         const bool nok = n + 4 <= p.N;
         f32x4 ba = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) ba = *reinterpret_cast<const f32x4*>(p.bias + (nok ? n : 0));
+        const f32x4 sa = lns(n, nok);
 #pragma unroll
         for (int j = 0; j < WMT; ++j) {
           const int m = m0 + wm * 64 + j * 16 + frow;
-          f32x4 a4 = acc[WNT - 1][j] + ba;
+          f32x4 a4 = lncorr(acc[WNT - 1][j], j, sa) + ba;
           if (p.res) {
             const bf16x4 r4 = rg_load8(p.res, p.res_bytes, (nok && m < p.M) ? (int)(((long)m * p.ldr + n) * 2) : OOB);
 #pragma unroll
@@ -425,7 +464,8 @@ bool ring_gemm_ok(const GemmP& p, int batch, int n_cu) {
   static const int min_pct = getenv("CRG_GEMM_RING_MIN") ? atoi(getenv("CRG_GEMM_RING_MIN")) : 300;  // dev knob: least tiles, % of the CU count
   if (!on || batch != 1 || p.K % 64 || p.K < 128 || p.splits != 1) return false;
   if (p.epi != CRG_EPI_GEGLU && !(on >= 2 && p.epi == CRG_EPI_NONE)) return false;
-  if (p.bias_mode == CRG_BIAS_ROW || p.cvec || p.gstat || p.vt) return false;
+  if (p.bias_mode == CRG_BIAS_ROW || p.cvec || p.gstat || p.vt || p.rstat) return false;
+  if (p.ln_stat && (p.res || ((uintptr_t)p.ln_s & 15))) return false;
   const bool geglu = p.epi == CRG_EPI_GEGLU;
   if (geglu ? (p.N % 32 || (p.ldy & 3)) : (p.N % 8 || (p.ldy & 7) || ((uintptr_t)p.y & 15))) return false;
   if (p.res && ((p.ldr & 7) || ((uintptr_t)p.res & 15))) return false;
@@ -448,6 +488,7 @@ int launch_gemm_ring(crg_ctx* ctx, hipStream_t st, const GemmP& g, double flops,
   p.res = (const bf16*)g.res; p.ldr = g.ldr; p.res_bytes = g.res ? (unsigned)((double)g.M * g.ldr * 2) : 0;
   p.y = (bf16*)g.y; p.ldy = g.ldy; p.y_bytes = (unsigned)((double)g.M * g.ldy * 2);
   p.M = g.M; p.N = g.N; p.K = g.K; p.nk = g.K / 64;
+  p.ln_stat = g.ln_stat; p.ln_parts = g.ln_parts; p.ln_s = g.ln_s; p.ln_eps = g.ln_eps;
   p.tiles_m = (g.M + 255) / 256;
   p.tiles_n = (g.N + bn - 1) / bn;
   p.tile_count = p.tiles_m * p.tiles_n;
@@ -472,6 +513,8 @@ int launch_gemm_ring(crg_ctx* ctx, hipStream_t st, const GemmP& g, double flops,
   static const int stag = getenv("CRG_GEMM_RING_STAG") ? atoi(getenv("CRG_GEMM_RING_STAG")) : 1;  // dev knob: 0 = all eight waves in lockstep (round 3a)
   void (*kern)(RingP) = stag ? (geglu ? gemm_ring_kernel<4, true> : (wnt == 5 ? gemm_ring_kernel<5, false> : gemm_ring_kernel<4, false>))
                              : (geglu ? gemm_ring_kernel<4, true, false> : (wnt == 5 ? gemm_ring_kernel<5, false, false> : gemm_ring_kernel<4, false, false>));
+  if (g.ln_stat)  // LayerNorm epilogue: staggered schedule only
+    kern = geglu ? gemm_ring_kernel<4, true, true, true> : (wnt == 5 ? gemm_ring_kernel<5, false, true, true> : gemm_ring_kernel<4, false, true, true>);
   const size_t lds = (size_t)3 * (256 * 128 + bn * 128);
   if (int rc = crg_set_dyn_lds(ctx, reinterpret_cast<const void*>(kern), 160 * 1024, "gemm ring")) return rc;
   crg_prof_scope ps(ctx, st, wnt == 5 ? CRG_K_GEMM_W5 : CRG_K_GEMM_W4, flops, bytes);

@@ -42,6 +42,14 @@ struct GemmP {
   // vt[(m / vt_T) * (N - vt_n0) + n - vt_n0][m % vt_T] (row length vt_ld) instead of y: the V^T operand of crg_attention out of the
   // same launch as Q | K (gemm_glds_kernel, paired epilogue; null = none)
   bf16* vt; int vt_n0, vt_T; long vt_ld;
+  // LayerNorm row statistics, PRODUCER side (crg_gemm_args.row_stats): rstat[0][q][m] / rstat[1][q][m] = sum / sum of squares of the
+  // finished (rounded) outputs of row m over the columns of partial q - q = 2 * n-tile + wave column of the paired epilogue, i.e.
+  // rstat_parts = 2 * tiles_n partials per row (the split-K reduce writes whole-row sums into partial 0 and zeros into the rest)
+  float* rstat; int rstat_parts;
+  // LayerNorm as an epilogue correction, CONSUMER side (crg_gemm_args.ln_stats): the GEMM runs on the RAW rows x with the weight
+  // W o gamma, and  y = rstd_m * (acc - mean_m * ln_s[n]) + bias'[n]  with (mean, rstd) folded from the producer's ln_parts partials per
+  // row (planes of ln_parts * M floats), ln_s[n] = sum_k (W o gamma)[n][k] over the ROUNDED weight, bias' = W beta + bias (in p.bias)
+  const float* ln_stat; int ln_parts; const float* ln_s; float ln_eps;
   // GroupNorm(+SiLU) of the finished output (crg_conv_args.gn_y): when the launch is split along K and a (sample, group) slab fits one
   // block, the kernel that sums the K slices normalises as well (splitk_reduce_gn_kernel) - no reduce launch and no second read of y
   const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_groups, gn_silu, gn_hw; void* gn_y;
@@ -277,12 +285,17 @@ __device__ __forceinline__ int unpair_col(int pos) {  // LDS row position within
 // 160 to 214 VGPRs (+ 80 accumulators: past 256, i.e. ONE block per CU for every GEMM, statistics or not) - that kernel therefore
 // takes it as a template parameter; the one-block-per-CU conv kernels, whose register budget is fixed by their launch bounds, keep
 // the runtime form (no extra instantiations, no spills).
-template <int WNT, int WMT, int SM = 2>
+// RS: this instantiation also emits the LayerNorm row statistics of its outputs (p.rstat, see GemmP): per row the sum and the sum of
+// squares of the ROUNDED values this wave stores (16 WNT columns), folded over the four 16-lane groups that share a row - two
+// ds_bpermute per value - and stored by the lanes of group 0: 64 contiguous bytes per plane and 16-row tile.
+template <int WNT, int WMT, int SM = 2, bool RS = false>
 __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)[WNT][WMT], int m0, int n0, int wm, int wn, int frow,
                                                     int fq, int bz, const bf16x8 (&r2)[WNT / 2 > 0 ? WNT / 2 : 1][WMT],
                                                     const bf16x4 (&r1)[WMT], bool has_res, const f32x4 (&bpre)[WNT], bool has_bias) {
   bf16* Y = reinterpret_cast<bf16*>(p.y) + (long)bz * p.y_bs;
   const int nb = n0 + wn * (16 * WNT);
+  const long rs_plane = (long)p.rstat_parts * p.M;
+  float* RS1 = RS ? p.rstat + (long)((n0 / (32 * WNT)) * 2 + wn) * p.M : nullptr;
   auto body = [&](auto STATSc) {
     constexpr bool STATS = decltype(STATSc)::value;
     constexpr int NG = WNT / 2 > 0 ? WNT / 2 : 1;
@@ -305,6 +318,7 @@ __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)
       }
       const float brow = (p.bias_mode == CRG_BIAS_ROW) ? p.bias[valid ? m : 0] : 0.f;
       const float* cv = p.cvec ? p.cvec + (long)((valid ? m : 0) / p.cvec_rows) * p.cvec_ld : nullptr;
+      float q1 = 0.f, q2 = 0.f;  // RS: this lane's share of row m
       auto finish = [&](f32x4 v, int i, int n) {
         if (has_bias) v += bpre[i];
         else if (p.bias_mode == CRG_BIAS_ROW) v += brow;
@@ -334,6 +348,14 @@ __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)
           o[4 + e] = (bf16)b[e];
         }
         if (valid) *reinterpret_cast<bf16x8*>(Y + (long)m * p.ldy + n) = o;
+        if constexpr (RS) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = (float)o[e];
+            q1 += f;
+            q2 = __builtin_fmaf(f, f, q2);
+          }
+        }
         if constexpr (STATS) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -355,6 +377,14 @@ __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (bf16)a[e];
           if (valid) *reinterpret_cast<bf16x4*>(Y + (long)m * p.ldy + n) = o;
+          if constexpr (RS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float f = (float)o[e];
+              q1 += f;
+              q2 = __builtin_fmaf(f, f, q2);
+            }
+          }
           if constexpr (STATS) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -363,6 +393,16 @@ __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)
               t2[e] = __builtin_fmaf(f, f, t2[e]);
             }
           }
+        }
+      }
+      if constexpr (RS) {
+        q1 += __shfl_xor(q1, 16);
+        q2 += __shfl_xor(q2, 16);
+        q1 += __shfl_xor(q1, 32);
+        q2 += __shfl_xor(q2, 32);
+        if (fq == 0 && valid) {
+          RS1[m] = q1;
+          RS1[rs_plane + m] = q2;
         }
       }
       if constexpr (STATS) {

@@ -93,7 +93,8 @@ class GraphedModule:
         consts = {k: kw[k] for k in self.const_args if kw.get(k) is not None}
         dyn = {k: v for k, v in kw.items() if k not in consts and torch.is_tensor(v)}
         other = {k: v for k, v in kw.items() if k not in consts and not torch.is_tensor(v)}
-        key = (self._sig(x), tuple((k, self._sig(v)) for k, v in sorted(dyn.items())),
+        dup = bool(getattr(x, "_crg_cfg_dup", False))  # ops.mark_cfg_dup: a different kernel sequence, hence a different graph
+        key = (self._sig(x), dup, tuple((k, self._sig(v)) for k, v in sorted(dyn.items())),
                tuple((k, id(v), v._version, self._sig(v)) for k, v in sorted(consts.items())), tuple(sorted(other.items())))
         if self.broken:
             return self.module(x, **kw)
@@ -129,6 +130,8 @@ class GraphedModule:
         h = L.ctx(dev.index if dev.index is not None else torch.cuda.current_device())
         L.check(L.load().crg_ctx_reserve(h, C.c_size_t(self.scratch_bytes)), h, "crg_ctx_reserve")
         sx = x.clone()
+        if getattr(x, "_crg_cfg_dup", False):
+            sx._crg_cfg_dup = True
         sdyn = {k: v.clone() for k, v in dyn.items()}
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))

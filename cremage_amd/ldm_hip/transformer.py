@@ -212,9 +212,11 @@ class CrossAttention(nn.Module):
         self._kv = (context, context._version, wkeys, out)
         return out
 
-    def forward(self, x, context=None, mask=None, residual=None, ln: Optional[nn.LayerNorm] = None):
+    def forward(self, x, context=None, mask=None, residual=None, ln: Optional[nn.LayerNorm] = None, dup: bool = False):
         """`ln` (not in the reference's signature; passed by BasicTransformerBlock): the LayerNorm in front of this attention.
-        Its application is this module's job then - fused into the projection launch where ops.ln_linear_ok allows."""
+        Its application is this module's job then - fused into the projection launch where ops.ln_linear_ok allows.
+        `dup` (cross-attention only): x and residual are ONE half of a CFG-doubled batch whose halves are identical up to here
+        (ops.mark_cfg_dup); the context holds both halves.  The query projection runs once, q and the residual are duplicated."""
         if exists(mask):
             raise NotImplementedError("attention masks are never passed on the SD path (attention.py:648-652)")
         fused = self._fused(x.dtype)
@@ -263,6 +265,9 @@ class CrossAttention(nn.Module):
             return ops.linear(out, _eff(self, self.to_out[0].weight, "out"), self.to_out[0].bias, residual=residual)
         else:
             q = project(_eff(self, self.to_q.weight, "q"))
+            if dup:
+                q = ops.dup_batch(q)
+                residual = ops.dup_batch(residual) if residual is not None else None
             k, vt, nk, ipa = self._project_kv(context, x.dtype)
         att = (lambda kk, vv, n: ops.attention_rows_v(q, kk, vv, self.heads, self.scale)) if fused else \
               (lambda kk, vv, n: ops.attention(q, kk, vv, self.heads, n, self.scale))
@@ -308,14 +313,21 @@ class BasicTransformerBlock(nn.Module):
     def _ln(norm: nn.LayerNorm, x):
         return ops.layer_norm(x, norm.weight, norm.bias, norm.eps)
 
-    def forward(self, x, context=None):
-        return self._forward(x, context)
+    def forward(self, x, context=None, cfg_dup: bool = False):
+        return self._forward(x, context, cfg_dup)
 
-    def _forward(self, x, context=None):
+    def cfg_dup_ok(self) -> bool:
+        """Can this block take ONE half of a CFG-doubled batch and hand back both (see CrossAttention.forward, `dup`)?  Its first
+        attention must not read the conditioning."""
+        return not self.disable_self_attn
+
+    def _forward(self, x, context=None, cfg_dup: bool = False):
         # x = attn1(norm1(x)) + x; x = attn2(norm2(x), ctx) + x; x = ff(norm3(x)) + x (attention.py:908-912).  The LayerNorms are
         # handed to the consumers, which fuse them into their first GEMM launch where the kernel takes the shape
         x = self.attn1(x, context=context if self.disable_self_attn else None, residual=x, ln=self.norm1)
-        x = self.attn2(x, context=context, residual=x, ln=self.norm2)
+        x = self.attn2(x, context=context, residual=x, ln=self.norm2, dup=cfg_dup and context is not None)
+        if cfg_dup and context is None:
+            x = ops.dup_batch(x)
         x = self.ff(x, residual=x, ln=self.norm3)
         return x
 
@@ -345,13 +357,22 @@ class SpatialTransformer(nn.Module):
         self.proj_out = zero_module(Conv2d(inner_dim, in_channels, kernel_size=1, stride=1, padding=0))
         _lora_lists(self, "proj_out", inner_dim, in_channels, self.lora_ranks, conv=True)
 
-    def forward(self, x, context=None):
+    def cfg_dup_ok(self) -> bool:
+        return len(self.transformer_blocks) > 0 and self.transformer_blocks[0].cfg_dup_ok()
+
+    def forward(self, x, context=None, cfg_dup: bool = False):
+        """`cfg_dup` (test cfg_dup_ok first): x is one half of a CFG-doubled batch with identical halves (ops.mark_cfg_dup), the
+        context holds both; GroupNorm, proj_in and the first block's self-attention run once, the result has the full batch."""
         x = ops.to_channels_last(x)
         b, c, h, w = x.shape
         x_in = ops.tokens_of(x)
         xn = self.norm(x)
         t = ops.linear(ops.tokens_of(xn), _eff(self, self.proj_in.weight, "proj_in"), self.proj_in.bias)
-        for block in self.transformer_blocks:
+        for i, block in enumerate(self.transformer_blocks):
+            if cfg_dup and i == 0:
+                t = block(t, context=context, cfg_dup=True)
+                x_in = ops.dup_batch(x_in)
+                continue
             t = block(t, context=context)
         # the block's output feeds the next ResBlock's GroupNorm: its statistics come out of this launch's epilogue
         y = ops.linear(t, _eff(self, self.proj_out.weight, "proj_out"), self.proj_out.bias, residual=x_in, gn_hw=h * w)

@@ -327,16 +327,61 @@ class UNetModel(nn.Module):
         h = self.out[2](h)
         return ops.nhwc_to_nchw(h, x.dtype if x.dtype in (torch.float32, ops.HALF) else torch.float32).to(x.dtype)
 
-    def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
+    # -- CFG-shared prefix (ops.mark_cfg_dup) ---------------------------------------------------------
+    def _cfg_split_index(self):
+        """Index of the first input block that reads the conditioning, if it can take a half batch and hand back both halves
+        (a ResBlock followed by a SpatialTransformer whose first attention is a self-attention), else None."""
+        r = self.__dict__.get("_crg_cfg_split", False)
+        if r is False:
+            r = None
+            for i, m in enumerate(self.input_blocks):
+                sts = [l for l in m if isinstance(l, SpatialTransformer)]
+                if sts:
+                    layers = list(m)
+                    if len(sts) == 1 and layers[-1] is sts[0] and sts[0].cfg_dup_ok() and all(isinstance(l, TimestepBlock) for l in layers[:-1]):
+                        r = i
+                    break
+            self.__dict__["_crg_cfg_split"] = r
+        return r
+
+    def _input_blocks(self, x, cdt, emb, context, cfg_dup: bool):
+        """The encoder half (openaimodel.py:804-806): returns (h, hs).  With `cfg_dup` - x is cat([x'] * 2) and the timesteps are
+        doubled likewise, the caller's promise - everything before the first cross-attention runs on ONE half: both halves would
+        compute the same values there (conv_in, the first ResBlock, GroupNorm + proj_in, LayerNorm + Q | K | V, the 64x64 self-attention,
+        its out-projection, LayerNorm + to_q)."""
+        split = self._cfg_split_index() if (cfg_dup and ops.CFG_SHARE and x.shape[0] % 2 == 0 and context is not None) else None
+        hs = []
+        if split is None:
+            h = ops.nchw_to_nhwc(x, cdt)
+            for module in self.input_blocks:
+                h = module(h, emb, context)
+                hs.append(h)
+            return h, hs
+        half = x.shape[0] // 2
+        emb_h = emb[:half]
+        emb_h._crg_emb_out = {k: v[:half] for k, v in emb._crg_emb_out.items()}
+        h = ops.nchw_to_nhwc(x[:half], cdt)
+        for i, module in enumerate(self.input_blocks):
+            if i < split:
+                h = module(h, emb_h, context)
+                hs.append(ops.dup_batch(h))  # the skip connection feeds an output block, which runs the whole batch
+            elif i == split:
+                layers = list(module)
+                for layer in layers[:-1]:
+                    h = layer(h, emb_h)
+                h = layers[-1](h, context, cfg_dup=True)
+                hs.append(h)
+            else:
+                h = module(h, emb, context)
+                hs.append(h)
+        return h, hs
+
+    def forward(self, x, timesteps=None, context=None, y=None, cfg_dup: bool = False, **kwargs):
         """x [N, C, H, W] (any float dtype, NCHW) , timesteps [N] (may be fractional), context [N, T, D]
-        -> eps [N, C_out, H, W] in x.dtype (openaimodel.py:780-816)."""
+        -> eps [N, C_out, H, W] in x.dtype (openaimodel.py:780-816).  `cfg_dup` (or ops.mark_cfg_dup(x)): see _input_blocks."""
         assert y is None, "must specify y if and only if the model is class-conditional"
         cdt, emb, context = self._prologue(timesteps, context)
-        hs = []
-        h = ops.nchw_to_nhwc(x, cdt)
-        for module in self.input_blocks:
-            h = module(h, emb, context)
-            hs.append(h)
+        h, hs = self._input_blocks(x, cdt, emb, context, cfg_dup or getattr(x, "_crg_cfg_dup", False))
         h = self.middle_block(h, emb, context)
         for module in self.output_blocks:
             h = module((h, hs.pop()), emb, context)

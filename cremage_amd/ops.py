@@ -253,6 +253,36 @@ def image_of(t: torch.Tensor, h: int, w: int) -> torch.Tensor:
     return t.reshape(n, h, w, c).permute(0, 3, 1, 2)
 
 
+# ---------------------------------------------------------------------------------- CFG-shared prefix
+# Classifier-free guidance by batch doubling (ldm_wrapper_for_k_diffusion.py:67-93) hands the UNet cat([x] * 2) with cat([t] * 2): until
+# the first cross-attention reads the (different) conditioning of the two halves, both halves compute the same values.  The sampler
+# wrapper of this package marks such an input (never inferred from data); the UNet then runs that prefix on one half and duplicates
+# the activations where the halves start to differ.  CRG_CFG_SHARE=0 (dev knob, A/B) runs the whole batch as before.
+CFG_SHARE = __import__("os").environ.get("CRG_CFG_SHARE", "1") != "0"
+
+
+def mark_cfg_dup(x: torch.Tensor) -> torch.Tensor:
+    """Caller's promise: x == cat([h, h]) along the batch dim and so are the timesteps that go with it."""
+    x._crg_cfg_dup = True
+    return x
+
+
+def dup_batch(t: torch.Tensor) -> torch.Tensor:
+    """cat([t, t], dim 0) of a token tensor [B, T, C] or of a channels-last image (strides kept); one copy kernel.  The GroupNorm
+    statistics riding on an image (32-row blocks, sample-major) are duplicated with it."""
+    if t.dim() == 4:
+        v = t.permute(0, 2, 3, 1)
+        if not v.is_contiguous():
+            v = to_channels_last(t).permute(0, 2, 3, 1)
+        out = torch.cat([v, v], 0).permute(0, 3, 1, 2)
+        g = getattr(t, "_crg_gn", None)
+        if g is not None and g[1] == t._version:
+            out._crg_gn = (torch.cat([g[0], g[0]], 1), out._version, g[2])
+        return out
+    t = t.contiguous()
+    return torch.cat([t, t], 0)
+
+
 def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """Contiguous NCHW tensor -> channels-last tensor of `dtype` (one transpose+cast kernel)."""
     _need_cuda(x)

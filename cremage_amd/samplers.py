@@ -119,7 +119,10 @@ class CompVisDenoiser(DiscreteSchedule):
 
     def forward(self, input, sigma, **kwargs):
         c_out, c_in = [append_dims(x, input.ndim) for x in self.get_scalings(sigma)]
-        eps = self.get_eps(input * c_in, self.sigma_to_t(sigma), **kwargs)
+        x_in = input * c_in
+        if getattr(input, "_crg_cfg_dup", False):  # a batch-doubled input stays one under a per-sample scaling of equal sigmas
+            x_in._crg_cfg_dup = True
+        eps = self.get_eps(x_in, self.sigma_to_t(sigma), **kwargs)
         return input + eps * c_out
 
 
@@ -170,7 +173,7 @@ class LDMWrapperForKDiffusion(nn.Module):
         x_in = torch.cat([x] * 2)
         sigma_in = torch.cat([sigma] * 2)
         _, c_in = [append_dims(v, x_in.ndim) for v in cv.get_scalings(sigma_in)]
-        return cv.get_eps(x_in * c_in, cv.sigma_to_t(sigma_in), cond=self._cat_cond())
+        return cv.get_eps(_mark_dup(x_in * c_in), cv.sigma_to_t(sigma_in), cond=self._cat_cond())
 
     def eps_tables(self, sigmas):
         """(c_in, t) of the CompVis wrapper for a whole vector of sigmas at once - the same elementwise arithmetic
@@ -186,7 +189,7 @@ class LDMWrapperForKDiffusion(nn.Module):
         already expanded to the doubled batch.  ONE elementwise launch builds cat([x] * 2) * c_in."""
         xx = torch.empty((2,) + tuple(x.shape), dtype=x.dtype, device=x.device)
         torch.mul(x.unsqueeze(0).expand_as(xx), c_in_i, out=xx)
-        return self.compviz_model.get_eps(xx.view((2 * x.shape[0],) + tuple(x.shape[1:])), t_row, cond=self._cat_cond())
+        return self.compviz_model.get_eps(_mark_dup(xx.view((2 * x.shape[0],) + tuple(x.shape[1:]))), t_row, cond=self._cat_cond())
 
     def fused_step_ok(self, x) -> bool:
         return (self.unconditional_conditioning is not None and self.unconditional_guidance_scale != 1. and x.is_cuda
@@ -196,13 +199,23 @@ class LDMWrapperForKDiffusion(nn.Module):
         uc, scale = self.unconditional_conditioning, self.unconditional_guidance_scale
         if uc is None or scale == 1.:
             return self.compviz_model(x, t, self.c)
-        x_in = torch.cat([x] * 2)
+        x_in = _mark_dup(torch.cat([x] * 2))
         t_in = torch.cat([t] * 2)
         e_t_uncond, e_t = self.compviz_model(x_in, t_in, cond=self._cat_cond()).chunk(2)
         return e_t_uncond + scale * (e_t - e_t_uncond)
 
     def forward(self, *args, **kwargs):
         return self.apply_model(*args, **kwargs)
+
+
+def _mark_dup(x_in):
+    """The UNet input built by batch doubling: both halves hold the same latents and timesteps (only the conditioning differs) -
+    said to the HIP UNet through a tensor attribute, which survives `apply_model` / `DiffusionWrapper.forward` of the reference's
+    container as well (they pass x on untouched, ddpm.py:1034, :1517-1519)."""
+    if x_in.is_cuda:
+        from . import ops
+        ops.mark_cfg_dup(x_in)
+    return x_in
 
 
 def to_d(x, sigma, denoised):
@@ -435,7 +448,7 @@ class DDIMSampler(object):
         if unconditional_conditioning is None or unconditional_guidance_scale == 1.:
             e_t = self.model.apply_model(x, t, c)
         else:
-            x_in = torch.cat([x] * 2)
+            x_in = _mark_dup(torch.cat([x] * 2))
             t_in = torch.cat([t] * 2)
             c_in = self._c_in if getattr(self, "_c_in", None) is not None else torch.cat([unconditional_conditioning, c])
             e_t_uncond, e_t = self.model.apply_model(x_in, t_in, c_in).chunk(2)

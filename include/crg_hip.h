@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CRG_VERSION 101
+#define CRG_VERSION 102
 
 typedef struct crg_ctx crg_ctx;
 
@@ -187,6 +187,18 @@ typedef struct {
    * row length vt_ld >= vt_tokens) instead of y, which then has vt_n0 columns: `to_q | to_k | to_v` of a self-attention
    * (attention.py:614,629,636) as ONE launch whose V third comes out as the V^T operand of crg_attention */
   void* vt; int vt_n0; int vt_tokens; int64_t vt_ld;
+  /* ---- nn.LayerNorm folded into the GEMM that consumes it, any K (attention.py:900-912: norm1 -> to_q | to_k | to_v, norm2 -> to_q,
+   * norm3 -> the GEGLU projection; sgm/modules/attention.py:724-847 for SDXL) -------------------------------------------------------
+   * PRODUCER side, `row_stats` (bf16 in / out, unbatched, plain epilogue, N % 8 == 0): the launch that writes the LayerNorm's input
+   * (proj_in, to_out + residual, net[2] + residual) also writes, per row m, the sum and the sum of squares of its rounded outputs as
+   * row_stats_parts = 2 * ceil(N / tile) column partials (tile = 160 when N % 160 == 0, else 128): fp32 [2][row_stats_parts][M].
+   * CONSUMER side, `ln_stats` (bf16 in / out, unbatched, no residual, epilogue NONE or GEGLU, a transposed range allowed): `a` holds the
+   * RAW rows x (the LayerNorm input), `w` the weight scaled by gamma and `bias` the folded bias (crg_pack_ln_weight), and
+   *     y = rstd_m * (a W'^T - mean_m * ln_colsum[n]) + bias[n]  =  LayerNorm(x) W^T + b
+   * with (mean_m, rstd_m) folded from the ln_parts partials per row of the producer's row_stats (fp32, eps = ln_eps, biased
+   * variance as nn.LayerNorm).  The normalised tensor never exists and no LayerNorm launch runs.  K = the LayerNorm width. */
+  float* row_stats; int row_stats_parts;
+  const float* ln_stats; int ln_parts; const float* ln_colsum; float ln_eps;
 } crg_gemm_args;
 int crg_gemm(crg_ctx* ctx, void* stream, const crg_gemm_args* args);
 
@@ -239,6 +251,15 @@ int crg_pack_weight(crg_ctx* ctx, void* stream, const void* src, int src_dtype, 
                     int ksize, void* dst_hi, void* dst_lo);
 /* bias for GEGLU packed the same way (fp32 in, fp32 out) */
 int crg_pack_geglu_bias(crg_ctx* ctx, void* stream, const float* src, int n_out2, float* dst);
+/* Operands of a GEMM that carries the LayerNorm in front of it as an epilogue correction (crg_gemm_args.ln_stats):
+ *   dst_w[o][k]   = half( W[r(o)][k] * gamma[k] )                    bf16 [n_out][n_in]
+ *   dst_colsum[o] = sum_k float(dst_w[o][k])                          fp32 [n_out]   (over the ROUNDED weight: what the MFMA multiplies,
+ *                                                                     so that mean * colsum cancels the mean's share of the product exactly)
+ *   dst_bias[o]   = sum_k W[r(o)][k] * beta[k] + bias[r(o)]           fp32 [n_out]   (bias may be NULL)
+ * r(o) = o for CRG_PACK_LINEAR, the GEGLU row interleave of crg_pack_weight for CRG_PACK_GEGLU.  src: [n_out][n_in] of src_dtype.
+ * Replaces the `weight` / `bias` of nn.LayerNorm (attention.py:900-902) together with the Linear behind it. */
+int crg_pack_ln_weight(crg_ctx* ctx, void* stream, const void* src, int src_dtype, const float* gamma, const float* beta,
+                       const float* bias, int kind, int n_out, int n_in, void* dst_w, float* dst_colsum, float* dst_bias);
 
 /* ---- attention: O = softmax(Q K^T * scale) V ---------------------------------------------------
  * Replaces the attention core of CrossAttentionOriginal.forward (attention.py:644-658), the sliced

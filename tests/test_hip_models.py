@@ -769,6 +769,54 @@ def test_c4_unit_img2img_768_properties():
     assert (im_1.cpu() - im_a[1:2].cpu()).abs().mean().item() < 2e-2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, BF])
+@pytest.mark.parametrize("model", ["unet", "controlled"])
+def test_cfg_shared_prefix_matches_full_batch(dtype, model):
+    """A batch-doubled call marked with ops.mark_cfg_dup (what the sampler wrapper does for classifier-free guidance,
+    ldm_wrapper_for_k_diffusion.py:67-93) runs conv_in .. the first self-attention on ONE half: the result must be the full-batch
+    result within the block tolerances (same arithmetic per sample; only tile configurations may differ with the batch size), for the
+    plain UNet, the ControlNet-hooked subclass with control residuals, the `cfg_dup=True` keyword, and through a hipGraph replay;
+    an unmarked call with DIFFERENT halves must be untouched by the feature."""
+    from cremage_amd import ops
+    from cremage_amd.graphs import GraphedModule
+    from cremage_amd.ldm_hip.unet import UNetModel
+    from cremage_amd.cldm_hip.cldm import ControlledUnetModel
+    meta, g = load_golden("unet_small_sd")
+    cfg = meta["cfg"]
+    cls = UNetModel if model == "unet" else ControlledUnetModel
+    m = prep(cls(**cfg), meta, dtype)
+    assert m._cfg_split_index() == 1
+    xh = synth_input("cfgdup.x", (2, 4, 16, 16), 5).to(DEV)
+    x = torch.cat([xh, xh])
+    t = torch.tensor([801.5, 333.25, 801.5, 333.25], device=DEV)
+    ctx = synth_input("cfgdup.ctx", (4, 77, cfg["context_dim"]), 6).to(DEV)
+    kw = {}
+    if model == "controlled":
+        with torch.no_grad():
+            m(x, timesteps=t, context=ctx)  # shapes of the 13 control residuals: the skips + the middle output
+        shapes = [(4, 64, 16, 16)] * 3 + [(4, 64, 8, 8)] + [(4, 128, 8, 8)] * 2 + [(4, 128, 4, 4)] + [(4, 256, 4, 4)] * 2 + [(4, 256, 2, 2)] * 4
+        kw["control"] = [synth_input(f"cfgdup.ctrl{i}", sh, 7, 0.1).to(DEV) for i, sh in enumerate(shapes)]
+    with torch.no_grad():
+        full = m(x.clone(), timesteps=t, context=ctx, **kw)
+        shared = m(ops.mark_cfg_dup(x.clone()), timesteps=t, context=ctx, **kw)
+        shared_kw = m(x.clone(), timesteps=t, context=ctx, cfg_dup=True, **kw)
+    assert torch.equal(shared, shared_kw)
+    tol = TOL_BLOCK[dtype]
+    close(shared, full.float().cpu(), tol, f"cfg-shared prefix vs full batch ({model})")
+    assert not torch.equal(shared[:2], shared[2:])  # the halves differ (different conditioning)
+    if model == "unet":
+        gm = GraphedModule(m, scratch_bytes=64 << 20)
+        with torch.no_grad():
+            yg = gm(ops.mark_cfg_dup(x.clone()), timesteps=t, context=ctx)
+            yg2 = gm(ops.mark_cfg_dup(x.clone()), timesteps=t, context=ctx)
+            yu = gm(x.clone(), timesteps=t, context=ctx)  # unmarked: its own graph, the full-batch kernel sequence
+        assert torch.equal(yg, shared) and torch.equal(yg2, shared) and torch.equal(yu, full) and len(gm._graphs) == 2
+        x2 = torch.cat([xh, synth_input("cfgdup.x2", (2, 4, 16, 16), 8).to(DEV)])
+        with torch.no_grad():
+            y2 = m(x2, timesteps=t, context=ctx)
+        assert not torch.allclose(y2[:2].float(), y2[2:].float())
+
+
 def test_hip_graph_replay_equals_eager():
     """hipGraph replay of the UNet call (cremage_amd.graphs) is bitwise the eager result, for changing x / t and after a
     context change (re-capture), on the SD-shaped small UNet."""

@@ -93,7 +93,12 @@ def test_linear_transposed_range(B, T, K, C):
     check(vt[:, :, :T].transpose(1, 2), ref[..., 2 * C:], BF, "v transposed")
     assert (vt[:, :, T:] == 0).all()
     whole = ops.linear(x.to(dev).to(BF), w.to(dev))
-    assert torch.equal(whole[..., :2 * C], qk) and torch.equal(whole[..., 2 * C:], vt[:, :, :T].transpose(1, 2))
+    if (B * T + 127) // 128 * (3 * C // 160) % 512 in range(1, 225) and (B * T + 127) // 128 * (3 * C // 160) > 512:
+        # without the transposed range this grid takes the K-split tail (another summation order for its last rows): close, not bitwise
+        check(whole[..., :2 * C], qk.float(), BF, "q | k vs the untransposed launch")
+        check(whole[..., 2 * C:], vt[:, :, :T].transpose(1, 2).float(), BF, "v vs the untransposed launch")
+    else:
+        assert torch.equal(whole[..., :2 * C], qk) and torch.equal(whole[..., 2 * C:], vt[:, :, :T].transpose(1, 2))
 
 
 def test_linear_ring_gemm():
