@@ -541,12 +541,9 @@ __global__ __launch_bounds__(256 * KG, ((XT != 0 || CRG_LB_A) && KG == 1 && WMT 
     if (kg == 0) {
       const int rl = lane < 16 * WMT ? lane : 16 * WMT - 1;
       const int mr = m0 + wm * (16 * WMT) + rl;
-      const float* q = p.ln_stat + (mr < p.M ? mr : p.M - 1);
-      const long plane = (long)p.ln_parts * p.M;
-      for (int u = 0; u < p.ln_parts; ++u) {
-        ln_a += q[(long)u * p.M];
-        ln_b += q[plane + (long)u * p.M];
-      }
+      const f32x2 ab = ln_fold_row(p.ln_stat, mr < p.M ? mr : p.M - 1, p.ln_parts);
+      ln_a = ab[0];
+      ln_b = ab[1];
       const int nb = n0 + wn * (16 * WNT);
 #pragma unroll
       for (int i = 0; i < WNT; ++i) {
@@ -1256,7 +1253,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(GemmP p) {
   bf16* Y = reinterpret_cast<bf16*>(p.y);
   const bf16* R = reinterpret_cast<const bf16*>(p.res);
   const int lane = threadIdx.x & 63;
-  const long plane = (long)p.rstat_parts * p.M;
   for (int m = p.slab_row0 + blockIdx.x * 4 + (threadIdx.x >> 6); m < p.M; m += gridDim.x * 4) {
     float q1 = 0.f, q2 = 0.f;
     for (int c = lane; c < n4; c += 64) {
@@ -1285,10 +1281,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(GemmP p) {
       q1 += __shfl_xor(q1, o);
       q2 += __shfl_xor(q2, o);
     }
-    if (lane < p.rstat_parts) {
-      p.rstat[(long)lane * p.M + m] = lane == 0 ? q1 : 0.f;
-      p.rstat[plane + (long)lane * p.M + m] = lane == 0 ? q2 : 0.f;
-    }
+    if (lane < p.rstat_parts) *reinterpret_cast<f32x2*>(p.rstat + ((long)m * p.rstat_parts + lane) * 2) = lane == 0 ? f32x2{q1, q2} : f32x2{0.f, 0.f};
   }
 }
 
@@ -1844,7 +1837,7 @@ extern "C" int crg_gemm(crg_ctx* ctx, void* stream, const crg_gemm_args* a) {
   }
   if (a->row_stats) {
     CRG_REQUIRE(ctx, a->prec == CRG_PREC_BF16 && a->a_dtype == CRG_BF16 && a->y_dtype == CRG_BF16 && a->batch == 1 && a->epilogue == CRG_EPI_NONE &&
-                         !a->gn_stats && !a->vt && !a->ln_stats && (a->N & 7) == 0 && a->row_stats_parts > 0 && ((uintptr_t)a->row_stats & 3) == 0,
+                         !a->gn_stats && !a->vt && !a->ln_stats && (a->N & 7) == 0 && a->row_stats_parts > 0 && a->row_stats_parts <= 64 && ((uintptr_t)a->row_stats & 15) == 0,
                 "gemm: row_stats need a plain unbatched bf16 GEMM with N %% 8 == 0 (no GroupNorm statistics / transposed range / LayerNorm epilogue)");
     p.rstat = a->row_stats; p.rstat_parts = a->row_stats_parts;
   }
@@ -1852,9 +1845,9 @@ extern "C" int crg_gemm(crg_ctx* ctx, void* stream, const crg_gemm_args* a) {
     CRG_REQUIRE(ctx, a->prec == CRG_PREC_BF16 && a->a_dtype == CRG_BF16 && a->y_dtype == CRG_BF16 && a->batch == 1 && !a->residual && !a->gn_stats &&
                          (a->epilogue == CRG_EPI_NONE || a->epilogue == CRG_EPI_GEGLU) && (a->bias_mode == CRG_BIAS_COL || !a->bias) && (a->N & 3) == 0,
                 "gemm: the LayerNorm epilogue needs an unbatched bf16 GEMM, N %% 4 == 0, epilogue NONE / GEGLU, no residual / row bias / statistics");
-    CRG_REQUIRE(ctx, a->ln_colsum && a->ln_parts > 0 && a->ln_parts <= 64 && a->ln_eps >= 0.f && (((uintptr_t)a->ln_colsum | (uintptr_t)a->ln_stats) & 15) == 0 &&
-                         (a->M & 3) == 0,
-                "gemm: ln_stats needs ln_colsum, 1..64 partials per row, 16-byte aligned pointers and M %% 4 == 0");
+    CRG_REQUIRE(ctx, a->ln_colsum && a->ln_parts >= 2 && a->ln_parts <= 16 && (a->ln_parts & 1) == 0 && a->ln_eps >= 0.f &&
+                         (((uintptr_t)a->ln_colsum | (uintptr_t)a->ln_stats) & 15) == 0,
+                "gemm: ln_stats needs ln_colsum, an even number of 2..16 partials per row and 16-byte aligned pointers");
     p.ln_stat = a->ln_stats; p.ln_parts = a->ln_parts; p.ln_s = a->ln_colsum; p.ln_eps = a->ln_eps;
   }
   const double flops = 2.0 * a->M * (double)a->N * a->K * a->batch;

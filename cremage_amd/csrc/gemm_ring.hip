@@ -259,13 +259,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(RingP p) {
     float rj[LNE ? WMT : 1], mj[LNE ? WMT : 1];
     if constexpr (LNE) {
       const int mr = m0 + wm * 64 + lane;
-      const float* q = p.ln_stat + (mr < p.M ? mr : p.M - 1);
-      const long plane = (long)p.ln_parts * p.M;
-      float a = 0.f, b = 0.f;
-      for (int u = 0; u < p.ln_parts; ++u) {
-        a += q[(long)u * p.M];
-        b += q[plane + (long)u * p.M];
-      }
+      const f32x2 ab = ln_fold_row(p.ln_stat, mr < p.M ? mr : p.M - 1, p.ln_parts);
+      const float a = ab[0], b = ab[1];
       const float invk = 1.0f / (float)p.K;
       const float mean = a * invk;
       float var = __builtin_fmaf(-mean, mean, b * invk);

@@ -42,13 +42,14 @@ struct GemmP {
   // vt[(m / vt_T) * (N - vt_n0) + n - vt_n0][m % vt_T] (row length vt_ld) instead of y: the V^T operand of crg_attention out of the
   // same launch as Q | K (gemm_glds_kernel, paired epilogue; null = none)
   bf16* vt; int vt_n0, vt_T; long vt_ld;
-  // LayerNorm row statistics, PRODUCER side (crg_gemm_args.row_stats): rstat[0][q][m] / rstat[1][q][m] = sum / sum of squares of the
+  // LayerNorm row statistics, PRODUCER side (crg_gemm_args.row_stats): rstat[m][q][0] / rstat[m][q][1] = sum / sum of squares of the
   // finished (rounded) outputs of row m over the columns of partial q - q = 2 * n-tile + wave column of the paired epilogue, i.e.
-  // rstat_parts = 2 * tiles_n partials per row (the split-K reduce writes whole-row sums into partial 0 and zeros into the rest)
+  // rstat_parts = 2 * tiles_n partials per row (the split-K reduce writes whole-row sums into partial 0 and zeros into the rest).
+  // Row-major per row so that the consumer fetches a row's partials with a few 16-byte loads issued together (one latency)
   float* rstat; int rstat_parts;
   // LayerNorm as an epilogue correction, CONSUMER side (crg_gemm_args.ln_stats): the GEMM runs on the RAW rows x with the weight
   // W o gamma, and  y = rstd_m * (acc - mean_m * ln_s[n]) + bias'[n]  with (mean, rstd) folded from the producer's ln_parts partials per
-  // row (planes of ln_parts * M floats), ln_s[n] = sum_k (W o gamma)[n][k] over the ROUNDED weight, bias' = W beta + bias (in p.bias)
+  // row (ln_stat[m][q][2]), ln_s[n] = sum_k (W o gamma)[n][k] over the ROUNDED weight, bias' = W beta + bias (in p.bias)
   const float* ln_stat; int ln_parts; const float* ln_s; float ln_eps;
   // GroupNorm(+SiLU) of the finished output (crg_conv_args.gn_y): when the launch is split along K and a (sample, group) slab fits one
   // block, the kernel that sums the K slices normalises as well (splitk_reduce_gn_kernel) - no reduce launch and no second read of y
@@ -294,8 +295,7 @@ __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)
                                                     const bf16x4 (&r1)[WMT], bool has_res, const f32x4 (&bpre)[WNT], bool has_bias) {
   bf16* Y = reinterpret_cast<bf16*>(p.y) + (long)bz * p.y_bs;
   const int nb = n0 + wn * (16 * WNT);
-  const long rs_plane = (long)p.rstat_parts * p.M;
-  float* RS1 = RS ? p.rstat + (long)((n0 / (32 * WNT)) * 2 + wn) * p.M : nullptr;
+  float* RS1 = RS ? p.rstat + ((n0 / (32 * WNT)) * 2 + wn) * 2 : nullptr;
   auto body = [&](auto STATSc) {
     constexpr bool STATS = decltype(STATSc)::value;
     constexpr int NG = WNT / 2 > 0 ? WNT / 2 : 1;
@@ -400,10 +400,7 @@ __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)
         q2 += __shfl_xor(q2, 16);
         q1 += __shfl_xor(q1, 32);
         q2 += __shfl_xor(q2, 32);
-        if (fq == 0 && valid) {
-          RS1[m] = q1;
-          RS1[rs_plane + m] = q2;
-        }
+        if (fq == 0 && valid) *reinterpret_cast<f32x2*>(RS1 + (long)m * p.rstat_parts * 2) = f32x2{q1, q2};
       }
       if constexpr (STATS) {
         if ((j & 1) == 1) {
@@ -452,6 +449,36 @@ __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)
   else if constexpr (SM == 0) body(std::integral_constant<bool, false>{});
   else if (p.gstat) body(std::integral_constant<bool, true>{});
   else body(std::integral_constant<bool, false>{});
+}
+
+// (sum, sum of squares) of one row from its `parts` partials (stat[m][q][2], parts even, <= 16): all the 16-byte loads go out together,
+// clamped duplicates where there are fewer partials (one load latency, not one per partial)
+__device__ __forceinline__ f32x2 ln_fold_row(const float* stat, long m, int parts) {
+  const f32x4* q = reinterpret_cast<const f32x4*>(stat + m * parts * 2);
+  const int nq = parts >> 1;
+  float a = 0.f, b = 0.f;
+  if (nq <= 4) {
+    f32x4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = q[u < nq ? u : 0];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float k = u < nq ? 1.f : 0.f;
+      a += k * (t[u][0] + t[u][2]);
+      b += k * (t[u][1] + t[u][3]);
+    }
+  } else {
+    f32x4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = q[u < nq ? u : 0];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float k = u < nq ? 1.f : 0.f;
+      a += k * (t[u][0] + t[u][2]);
+      b += k * (t[u][1] + t[u][3]);
+    }
+  }
+  return f32x2{a, b};
 }
 
 template <int N>

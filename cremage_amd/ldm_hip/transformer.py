@@ -32,7 +32,6 @@ from .nn import Conv2d, Linear, Normalize, zero_module
 import os
 
 _SELF_QKV = os.environ.get("CRG_SELF_QKV", "1") != "0"  # dev knob: 0 = self-attention as fused Q|K GEMM + transposed-V GEMM (round-1 form)
-_SELF_VT = os.environ.get("CRG_SELF_VT", "1") != "0"    # dev knob: 0 = V stays row-major in the fused projection (round-2 form) at every level
 
 
 def exists(v):
@@ -113,12 +112,7 @@ class GEGLU_with_lora(nn.Module):
     def forward(self, x, ln: Optional[nn.LayerNorm] = None):
         """`ln`: the LayerNorm in front of this projection, to be applied to x first - fused into the GEMM launch where the
         row-resident kernel takes the shape (ops.ln_linear_ok), as a separate pass otherwise."""
-        w = _eff(self, self.proj.weight, "proj")
-        if ln is not None:
-            if ops.ln_linear_ok(x, w, act="geglu"):
-                return ops.ln_linear(x, ln.weight, ln.bias, ln.eps, w, self.proj.bias, act="geglu")
-            x = ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
-        return ops.linear(x, w, self.proj.bias, act="geglu")
+        return ops.ln_linear_auto(x, ln, _eff(self, self.proj.weight, "proj"), self.proj.bias, act="geglu")
 
 
 class FeedForward(nn.Module):
@@ -139,9 +133,10 @@ class FeedForward(nn.Module):
                                   nn.Dropout(dropout), Linear(inner_dim, dim_out)])
         _lora_lists(self, "net_2", inner_dim, dim_out, self.lora_ranks)
 
-    def forward(self, x, residual=None, ln: Optional[nn.LayerNorm] = None):
+    def forward(self, x, residual=None, ln: Optional[nn.LayerNorm] = None, out_stats: bool = False):
+        """`out_stats`: the result feeds the next block's LayerNorm - its row statistics come out of this launch (ops.linear, row_stats)."""
         h = self.net[0](x, ln=ln)
-        return ops.linear(h, _eff(self, self.net[2].weight, "net_2"), self.net[2].bias, residual=residual)
+        return ops.linear(h, _eff(self, self.net[2].weight, "net_2"), self.net[2].bias, residual=residual, row_stats=out_stats)
 
 
 # ---------------------------------------------------------------------------------------------- attention
@@ -212,57 +207,50 @@ class CrossAttention(nn.Module):
         self._kv = (context, context._version, wkeys, out)
         return out
 
-    def forward(self, x, context=None, mask=None, residual=None, ln: Optional[nn.LayerNorm] = None, dup: bool = False):
+    def forward(self, x, context=None, mask=None, residual=None, ln: Optional[nn.LayerNorm] = None, dup: bool = False, out_stats: bool = False):
         """`ln` (not in the reference's signature; passed by BasicTransformerBlock): the LayerNorm in front of this attention.
         Its application is this module's job then - fused into the projection launch where ops.ln_linear_ok allows.
         `dup` (cross-attention only): x and residual are ONE half of a CFG-doubled batch whose halves are identical up to here
-        (ops.mark_cfg_dup); the context holds both halves.  The query projection runs once, q and the residual are duplicated."""
+        (ops.mark_cfg_dup); the context holds both halves.  The query projection runs once, q and the residual are duplicated.
+        `out_stats`: the result (to_out + residual) feeds a LayerNorm - its row statistics come out of the to_out launch."""
         if exists(mask):
             raise NotImplementedError("attention masks are never passed on the SD path (attention.py:648-652)")
         fused = self._fused(x.dtype)
 
-        def project(w):  # LayerNorm (if any) + the projection of x, one launch when the shape allows
-            nonlocal x, ln
-            if ln is not None:
-                if ops.ln_linear_ok(x, w):
-                    return ops.ln_linear(x, ln.weight, ln.bias, ln.eps, w)
-                x, ln = ops.layer_norm(x, ln.weight, ln.bias, ln.eps), None
-            return ops.linear(x, w)
+        def project(w, transposed_from=None):  # LayerNorm (if any) + the projection of x: one launch wherever a fused route exists
+            return ops.ln_linear_auto(x, ln, w, transposed_from=transposed_from)
+
+        def out_proj(o):
+            return ops.linear(o, _eff(self, self.to_out[0].weight, "out"), self.to_out[0].bias, residual=residual, row_stats=out_stats)
         if context is None:
             wq, wk, wv = _eff(self, self.to_q.weight, "q"), _eff(self, self.to_k.weight, "k"), _eff(self, self.to_v.weight, "v")
             c = wq.shape[0]
             if self.ipa_num_tokens > 0:
                 raise NotImplementedError("ipa_num_tokens > 0 needs a context (attention.py:623-627)")
             wqkv = self._stack(wq, wk, wv) if fused else None
-            if fused and _SELF_QKV and ln is not None and ops.ln_linear_ok(x, wqkv, transposed_from=2 * c):
+            if fused and _SELF_QKV and ln is not None and not ops.ln_epi_ok(x, wqkv) and ops.ln_linear_ok(x, wqkv, transposed_from=2 * c):
                 # 64x64 level: LayerNorm + Q | K | V in ONE launch whose V third is written transposed, so that the 4096-token
                 # self-attention runs on the transposed-V flash kernel (the row-major-V variant is 10-20 % slower there)
                 qk, vt = ops.ln_linear(x, ln.weight, ln.bias, ln.eps, wqkv, transposed_from=2 * c)
-                out = ops.attention(qk[..., :c], qk[..., c:], vt, self.heads, x.shape[1], self.scale)
-                return ops.linear(out, _eff(self, self.to_out[0].weight, "out"), self.to_out[0].bias, residual=residual)
-            if fused and _SELF_QKV and _SELF_VT and x.dim() == 3 and x.shape[1] % 64 == 0 and (c // self.heads) in (40, 64, 80) \
+                return out_proj(ops.attention(qk[..., :c], qk[..., c:], vt, self.heads, x.shape[1], self.scale))
+            if fused and _SELF_QKV and x.dim() == 3 and x.shape[1] % 64 == 0 and (c // self.heads) in (40, 64, 80) \
                     and ops.linear_transposed_ok(x, wqkv, 2 * c):
                 # head dims with an LDS-DMA / pipelined attention kernel (they stage V^T): the V third of the fused projection comes
-                # out transposed from the GEMM's own epilogue.  Device time in a graph, 8 x 1024 tokens, d 80: attention 43.6 -> 30.2 us;
+                # out transposed from the GEMM's own epilogue (LayerNorm: as an epilogue correction of the same launch when x carries
+                # its producer's row statistics).  Device time in a graph, 8 x 1024 tokens, d 80: attention 43.6 -> 30.2 us;
                 # SDXL 4 x 4096, d 64: 256 -> 205 us (tools/attn_vt_probe.py)
-                if ln is not None:
-                    x, ln = ops.layer_norm(x, ln.weight, ln.bias, ln.eps), None
-                qk, vt = ops.linear(x, wqkv, transposed_from=2 * c)
-                out = ops.attention(qk[..., :c], qk[..., c:], vt, self.heads, x.shape[1], self.scale)
-                return ops.linear(out, _eff(self, self.to_out[0].weight, "out"), self.to_out[0].bias, residual=residual)
+                qk, vt = project(wqkv, transposed_from=2 * c)
+                return out_proj(ops.attention(qk[..., :c], qk[..., c:], vt, self.heads, x.shape[1], self.scale))
             if fused and _SELF_QKV:
                 # self-attention: the three projections share their input -> ONE GEMM, q / k / v are column slices of its output
                 qkv = project(wqkv)
-                out = ops.attention_rows_v(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads, self.scale)
-                return ops.linear(out, _eff(self, self.to_out[0].weight, "out"), self.to_out[0].bias, residual=residual)
+                return out_proj(ops.attention_rows_v(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads, self.scale))
             if ln is not None:
                 x, ln = ops.layer_norm(x, ln.weight, ln.bias, ln.eps), None
             qk = ops.linear(x, self._stack(wq, wk))
             q, k = qk[..., :c], qk[..., c:]
             vt = ops.linear_transposed(x, wv)
-            nk, ipa = x.shape[1], None
-            out = ops.attention(q, k, vt, self.heads, nk, self.scale)
-            return ops.linear(out, _eff(self, self.to_out[0].weight, "out"), self.to_out[0].bias, residual=residual)
+            return out_proj(ops.attention(q, k, vt, self.heads, x.shape[1], self.scale))
         else:
             q = project(_eff(self, self.to_q.weight, "q"))
             if dup:
@@ -275,7 +263,7 @@ class CrossAttention(nn.Module):
         if ipa is not None:  # attention.py:660-681
             out_ipa = att(ipa[0], ipa[1], ipa[2])
             ops.axpby_(out, out_ipa, float(self.ipa_scale), 1.0)
-        return ops.linear(out, _eff(self, self.to_out[0].weight, "out"), self.to_out[0].bias, residual=residual)
+        return out_proj(out)
 
 
 CrossAttentionOriginal = CrossAttention
@@ -324,11 +312,15 @@ class BasicTransformerBlock(nn.Module):
     def _forward(self, x, context=None, cfg_dup: bool = False):
         # x = attn1(norm1(x)) + x; x = attn2(norm2(x), ctx) + x; x = ff(norm3(x)) + x (attention.py:908-912).  The LayerNorms are
         # handed to the consumers, which fuse them into their first GEMM launch where the kernel takes the shape
-        x = self.attn1(x, context=context if self.disable_self_attn else None, residual=x, ln=self.norm1)
-        x = self.attn2(x, context=context, residual=x, ln=self.norm2, dup=cfg_dup and context is not None)
+        # Each producer of a LayerNorm input (to_out + residual twice, net[2] + residual when another block follows) hands the consumer
+        # its row statistics, so that the LayerNorm is an epilogue correction of the consuming GEMM (ops.linear, ln=)
+        st = ops.ln_epi_wanted(x.shape[-1])
+        x = self.attn1(x, context=context if self.disable_self_attn else None, residual=x, ln=self.norm1, out_stats=st)
+        x = self.attn2(x, context=context, residual=x, ln=self.norm2, dup=cfg_dup and context is not None,
+                       out_stats=ops.ln_epi_wanted(x.shape[-1], geglu=True))
         if cfg_dup and context is None:
             x = ops.dup_batch(x)
-        x = self.ff(x, residual=x, ln=self.norm3)
+        x = self.ff(x, residual=x, ln=self.norm3, out_stats=st and getattr(self, "_crg_next_is_block", False))
         return x
 
 
@@ -367,8 +359,11 @@ class SpatialTransformer(nn.Module):
         b, c, h, w = x.shape
         x_in = ops.tokens_of(x)
         xn = self.norm(x)
-        t = ops.linear(ops.tokens_of(xn), _eff(self, self.proj_in.weight, "proj_in"), self.proj_in.bias)
+        t = ops.linear(ops.tokens_of(xn), _eff(self, self.proj_in.weight, "proj_in"), self.proj_in.bias,
+                       row_stats=ops.ln_epi_wanted(self.proj_in.weight.shape[0]))  # feeds the first block's norm1
+        nb = len(self.transformer_blocks)
         for i, block in enumerate(self.transformer_blocks):
+            block._crg_next_is_block = i + 1 < nb  # its feed-forward output then feeds another LayerNorm
             if cfg_dup and i == 0:
                 t = block(t, context=context, cfg_dup=True)
                 x_in = ops.dup_batch(x_in)

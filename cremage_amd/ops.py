@@ -133,8 +133,6 @@ class TensorKeyedCache:
         TensorKeyedCache.generation += 1
 
 
-_ROWRES = __import__("os").environ.get("CRG_ROWRES", "0") != "0"  # dev knob: 1 = route residual-free K = 320 GEMMs with >= 16384 rows to the row-resident kernel
-# (round 3, device time inside a captured graph, tools/lin_probe.py, 32768 x 320 x 320: 16.4 us row-resident vs 15.7 us on crg_gemm - off)
 _pack_cache = TensorKeyedCache()
 _f32_cache = TensorKeyedCache()
 
@@ -169,13 +167,85 @@ def _gn_stats_of(t: torch.Tensor, hw: int) -> Optional[torch.Tensor]:
     return g[0]
 
 
+# ---------------------------------------------------------------------------------- LayerNorm as a GEMM epilogue
+# nn.LayerNorm in front of a Linear (attention.py:900-912) never runs as a launch of its own when the LayerNorm's INPUT was written by a
+# GEMM of this library: that producer hands over per-row (sum, sum of squares) partials (crg_gemm_args.row_stats, riding on the
+# tensor as `_crg_ln = (stats, version)` like the GroupNorm channel above), and the consuming GEMM runs on the raw rows with W o gamma
+# and corrects its accumulators in the epilogue (crg_gemm_args.ln_stats).  Any width K; the K = 320 row-resident kernel (crg_ln_gemm)
+# stays the route of the 64x64 level unless CRG_LN_EPI_320 says otherwise.
+_env = __import__("os").environ
+LN_EPI = _env.get("CRG_LN_EPI", "1") != "0"          # dev knob (A/B): 0 = stand-alone layernorm launches as in round 3
+# K = 320 (the 64x64 level, where crg_ln_gemm exists): 0 = row-resident kernel for every consumer (round 3), 1 (default) = the plain
+# projections on the epilogue route (device time in a graph, tools/lnepi_probe.py: LN + Q | K | V 43.4 -> 40.6 us, LN + to_q 19.1 -> 16.6),
+# the GEGLU projection stays row-resident (76.8 us against 95.7 on the epilogue route), 2 = the GEGLU projection as well
+LN_EPI_320 = int(_env.get("CRG_LN_EPI_320", "1"))
+
+
+def row_stats_parts(n: int) -> int:
+    """Column partials per row the producer writes for an N-wide output (include/crg_hip.h: 2 * ceil(N / tile), tile 160 | 128)."""
+    bn = 160 if n % 160 == 0 else 128
+    return 2 * ((n + bn - 1) // bn)
+
+
+def ln_epi_wanted(width: int, geglu: bool = False) -> bool:
+    """Should the producer of a LayerNorm input of this width emit row statistics - would its consumer (the GEGLU projection if `geglu`,
+    else a plain projection) use them?"""
+    return LN_EPI and row_stats_parts(width) <= 16 and (width != 320 or LN_EPI_320 >= (2 if geglu else 1))
+
+
+def _ln_stats_of(x: torch.Tensor) -> Optional[torch.Tensor]:
+    g = getattr(x, "_crg_ln", None)
+    K = x.shape[-1]
+    if g is None or g[1] != x._version or g[0].shape[0] != x.numel() // K or g[0].shape[1] != row_stats_parts(K) or g[0].shape[1] > 16:
+        return None
+    return g[0]
+
+
+def ln_epi_ok(x: torch.Tensor, weight: torch.Tensor, act: Optional[str] = None) -> bool:
+    """Can `linear(x, weight, ..., ln=...)` run - does x carry valid row statistics and does the GEMM take the shape?"""
+    if not (LN_EPI and x.is_cuda and x.dtype == HALF and x.is_contiguous() and act in (None, "geglu")):
+        return False
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = weight.shape[0]
+    if weight[0].numel() != K or K % 8 or N % (32 if act == "geglu" else 8):
+        return False
+    if K == 320 and LN_EPI_320 < (2 if act == "geglu" else 1):
+        return False
+    return _ln_stats_of(x) is not None
+
+
+def packed_ln_weight(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: Optional[torch.Tensor], geglu: bool):
+    """(W o gamma in the library's half type [N, K], column sums of that rounded image fp32 [N], folded bias W beta + b fp32 [N]) -
+    crg_pack_ln_weight; cached on the identity + version of all four sources (LoRA-merged weights arrive as their own tensors)."""
+    _need_cuda(w, gamma, beta, bias)
+    srcs = (w, gamma, beta) + ((bias,) if bias is not None else ())
+    r = _pack_cache.get(srcs, ("ln", geglu, bias is not None))
+    if r is not None:
+        return r
+    src = w.detach().reshape(w.shape[0], -1).contiguous()
+    if src.dtype not in _DT:
+        src = src.float()
+    n_out, n_in = src.shape
+    dw = torch.empty((n_out, n_in), dtype=HALF, device=w.device)
+    ds = torch.empty((n_out,), dtype=torch.float32, device=w.device)
+    db = torch.empty((n_out,), dtype=torch.float32, device=w.device)
+    g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+    bb = bias.detach().float().contiguous() if bias is not None else None
+    h = _h(w)
+    L.check(L.load().crg_pack_ln_weight(h, _st(), _p(src), _dt(src), _p(g32), _p(b32), _p(bb), L.PACK_GEGLU if geglu else L.PACK_LINEAR, n_out, n_in,
+                                        _p(dw), _p(ds), _p(db)), h, "crg_pack_ln_weight")
+    return _pack_cache.put(srcs, ("ln", geglu, bias is not None), (dw, ds, db))
+
+
 def _written(t: torch.Tensor) -> torch.Tensor:
     """A kernel of this library just wrote `t` in place through its raw pointer: tell PyTorch (bump `_version`), so that everything keyed
     on the version - the GroupNorm statistics riding on the tensor (`_crg_gn`), the cross-attention K / V cache, the weight caches -
     sees the write as it sees a torch in-place op.  A raw write through a VIEW bumps the shared counter of the base as well."""
     torch.autograd.graph.increment_version(t)
-    if hasattr(t, "_crg_gn"):
-        del t._crg_gn
+    for a in ("_crg_gn", "_crg_ln"):
+        if hasattr(t, a):
+            delattr(t, a)
     return t
 
 
@@ -390,14 +460,22 @@ def _gemm(h, **kw):
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            act: Optional[str] = None, out_dtype: Optional[torch.dtype] = None, gn_hw: Optional[int] = None,
-           transposed_from: Optional[int] = None):
+           transposed_from: Optional[int] = None, row_stats: bool = False, ln=None):
     """y = act(x @ weight^T + bias) + residual over the last dim of x.
     weight: [N, K] (nn.Linear) or [N, K, 1, 1] (1x1 conv).  act: None | 'silu' | 'geglu'.
     gn_hw: y (as an image of gn_hw tokens per sample) feeds a GroupNorm - emit its statistics side channel (bf16 only, see above).
     transposed_from = n0 (test linear_transposed_ok first; x must be [B, T, K]): output columns >= n0 are returned as a SECOND tensor
     [B, N - n0, ld], ld = roundup(T, 8), transposed per sample - the V^T operand of `attention` out of the same launch as Q | K; the
-    first tensor then has n0 columns."""
+    first tensor then has n0 columns.
+    row_stats: y feeds an nn.LayerNorm - emit its row-statistics side channel where the path supports it (bf16, plain epilogue).
+    ln = (gamma, beta, eps) (test ln_epi_ok first): y = act(LayerNorm(x) @ weight^T + bias) with the LayerNorm carried as an epilogue
+    correction on the statistics x brought along; x itself is read raw, the normalised tensor never exists."""
     _need_cuda(x, weight, bias, residual)
+    ln_stats = None
+    if ln is not None:
+        if not ln_epi_ok(x, weight, act) or residual is not None or gn_hw is not None or out_dtype not in (None, HALF):
+            raise L.CrgError("linear: ln= outside its domain (test ln_epi_ok; no residual / GroupNorm statistics / fp32 output)")
+        ln_stats = _ln_stats_of(x)
     x = x.contiguous()
     K = x.shape[-1]
     M = x.numel() // K
@@ -408,11 +486,13 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     out_dtype = out_dtype or x.dtype
     if split and out_dtype != torch.float32:
         raise L.CrgError("linear: fp32 (BF16X3) inputs produce fp32 outputs")
-    if _ROWRES and act is None and residual is None and gn_hw is None and out_dtype == HALF and M >= 16384 and ln_linear_ok(x, weight):
-        # K = 320 with many rows (the 64x64 level's to_out / proj_in / proj_out): the row-resident kernel without its LayerNorm
-        return ln_linear(x, None, None, 0.0, weight, bias, residual=residual)
     geglu = act == "geglu"
-    hi, lo = packed_weight(weight, L.PACK_GEGLU if geglu else L.PACK_LINEAR, split)
+    ln_s = None
+    if ln is not None:
+        hi, ln_s, ln_b = packed_ln_weight(weight, ln[0], ln[1], bias, geglu)
+        lo = None
+    else:
+        hi, lo = packed_weight(weight, L.PACK_GEGLU if geglu else L.PACK_LINEAR, split)
     n_out = N // 2 if geglu else N
     vt, vt_tokens, vt_ld = None, 0, 0
     if transposed_from is not None:
@@ -425,7 +505,9 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
             vt[:, :, vt_tokens:].zero_()
     y = torch.empty(x.shape[:-1] + (n_out,), dtype=out_dtype, device=x.device)
     b = None
-    if bias is not None:
+    if ln is not None:
+        b = ln_b  # W beta + bias, already in the packed row order
+    elif bias is not None:
         b = packed_geglu_bias(bias) if geglu else f32_vec(bias)
     if residual is not None:
         residual = residual.contiguous()
@@ -433,6 +515,10 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
             raise L.CrgError("linear: residual must match the output in shape and dtype")
     h = _h(x)
     stats = _gn_stats_buffer(M, N, gn_hw, x.dtype, out_dtype, x.device) if not geglu else None
+    rs = None
+    if row_stats and LN_EPI and stats is None and ln is None and act is None and vt is None and x.dtype == HALF and out_dtype == HALF and N % 8 == 0 \
+            and row_stats_parts(N) <= 16:
+        rs = torch.empty((M, row_stats_parts(N), 2), dtype=torch.float32, device=x.device)
     _gemm(h, a=x.data_ptr(), lda=K, a_bstride=0, w=hi.data_ptr(), ldw=K, w_bstride=0, w_lo=lo.data_ptr() if lo is not None else None,
           bias=b.data_ptr() if b is not None else None, bias_mode=L.BIAS_COL if b is not None else L.BIAS_NONE,
           residual=residual.data_ptr() if residual is not None else None, ldr=n_out, r_bstride=0,
@@ -440,10 +526,29 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
           epilogue={None: L.EPI_NONE, "silu": L.EPI_SILU, "geglu": L.EPI_GEGLU}[act],
           a_dtype=_act_dt(x), y_dtype=_DT[out_dtype], prec=_prec(x), a_is_weight=0, a_lo=None,
           gn_stats=stats.data_ptr() if stats is not None else None,
-          vt=vt.data_ptr() if vt is not None else None, vt_n0=transposed_from or 0, vt_tokens=vt_tokens, vt_ld=vt_ld)
+          vt=vt.data_ptr() if vt is not None else None, vt_n0=transposed_from or 0, vt_tokens=vt_tokens, vt_ld=vt_ld,
+          row_stats=rs.data_ptr() if rs is not None else None, row_stats_parts=rs.shape[1] if rs is not None else 0,
+          ln_stats=ln_stats.data_ptr() if ln_stats is not None else None, ln_parts=ln_stats.shape[1] if ln_stats is not None else 0,
+          ln_colsum=ln_s.data_ptr() if ln_s is not None else None, ln_eps=float(ln[2]) if ln is not None else 0.0)
     if stats is not None:
         y._crg_gn_pending = stats  # the caller that shapes y into an image attaches it (image_of_stats)
+    if rs is not None:
+        y._crg_ln = (rs, y._version)
     return (y, vt) if vt is not None else y
+
+
+def ln_linear_auto(x: torch.Tensor, ln, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: Optional[str] = None,
+                   transposed_from: Optional[int] = None):
+    """act(LayerNorm(x) @ weight^T + bias) by the cheapest route the shapes allow (`ln`: an nn.LayerNorm-like module with weight / bias /
+    eps, or None for no norm): the epilogue correction when x carries its producer's row statistics, the row-resident kernel for
+    K = 320, else layer_norm + linear.  `transposed_from`: the caller has tested linear_transposed_ok (or ln_linear_ok) for it."""
+    if ln is None:
+        return linear(x, weight, bias, act=act, transposed_from=transposed_from)
+    if ln_epi_ok(x, weight, act) and (transposed_from is None or linear_transposed_ok(x, weight, transposed_from)):
+        return linear(x, weight, bias, act=act, transposed_from=transposed_from, ln=(ln.weight, ln.bias, ln.eps))
+    if ln_linear_ok(x, weight, act, transposed_from):
+        return ln_linear(x, ln.weight, ln.bias, ln.eps, weight, bias, act=act, transposed_from=transposed_from)
+    return linear(layer_norm(x, ln.weight, ln.bias, ln.eps), weight, bias, act=act, transposed_from=transposed_from)
 
 
 def linear_transposed_ok(x: torch.Tensor, weight: torch.Tensor, n0: int) -> bool:

@@ -27,10 +27,10 @@ class CrossAttention(T.CrossAttention):
                          lora_weights=lora_weights)
         self.backend = backend
 
-    def forward(self, x, context=None, mask=None, additional_tokens=None, n_times_crossframe_attn_in_self=0, residual=None, ln=None):
+    def forward(self, x, context=None, mask=None, additional_tokens=None, n_times_crossframe_attn_in_self=0, residual=None, ln=None, **fused):
         if additional_tokens is not None or n_times_crossframe_attn_in_self:
             raise NotImplementedError("additional_tokens / cross-frame attention belong to the video models (out of scope)")
-        return super().forward(x, context=context, mask=mask, residual=residual, ln=ln)
+        return super().forward(x, context=context, mask=mask, residual=residual, ln=ln, **fused)
 
 
 MemoryEfficientCrossAttention = CrossAttention

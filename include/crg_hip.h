@@ -191,7 +191,8 @@ typedef struct {
    * norm3 -> the GEGLU projection; sgm/modules/attention.py:724-847 for SDXL) -------------------------------------------------------
    * PRODUCER side, `row_stats` (bf16 in / out, unbatched, plain epilogue, N % 8 == 0): the launch that writes the LayerNorm's input
    * (proj_in, to_out + residual, net[2] + residual) also writes, per row m, the sum and the sum of squares of its rounded outputs as
-   * row_stats_parts = 2 * ceil(N / tile) column partials (tile = 160 when N % 160 == 0, else 128): fp32 [2][row_stats_parts][M].
+   * row_stats_parts = 2 * ceil(N / tile) column partials (tile = 160 when N % 160 == 0, else 128): fp32 [M][row_stats_parts][2]
+   * (N <= 1280: at most 16 partials, which is what the consumer side takes).
    * CONSUMER side, `ln_stats` (bf16 in / out, unbatched, no residual, epilogue NONE or GEGLU, a transposed range allowed): `a` holds the
    * RAW rows x (the LayerNorm input), `w` the weight scaled by gamma and `bias` the folded bias (crg_pack_ln_weight), and
    *     y = rstd_m * (a W'^T - mean_m * ln_colsum[n]) + bias[n]  =  LayerNorm(x) W^T + b

@@ -101,6 +101,81 @@ def test_linear_transposed_range(B, T, K, C):
         assert torch.equal(whole[..., :2 * C], qk) and torch.equal(whole[..., 2 * C:], vt[:, :, :T].transpose(1, 2))
 
 
+@pytest.mark.parametrize("M,N,K,res", [(8192, 640, 640, True),      # 256 tiles of 128 rows -> 64-row tiles (D)
+                                       (32768, 320, 320, True),     # 512 tiles -> A, two blocks per CU
+                                       (2048, 1280, 1280, True),    # 128 tiles -> C (8 waves, in-block split-K)
+                                       (520, 1280, 1280, False),    # ragged M, C
+                                       (4096, 1280, 5120, True),    # SDXL net[2] at the 32x32 level: 256 tiles, K = 80 k-tiles -> split-K, statistics from the reduce
+                                       (1000, 648, 136, False)])    # N no multiple of the tile: a partial last n-tile
+def test_row_stats_side_channel(M, N, K, res):
+    """crg_gemm_args.row_stats: per row and column partial the sum / sum of squares of the ROUNDED outputs (the LayerNorm statistics
+    the consuming GEMM folds), from the paired epilogue of every tile configuration and from the split-K reduce; the output itself is
+    bitwise what the launch without the side channel writes."""
+    from cremage_amd import ops
+    dev = _dev()
+    x, w, b, r = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=K ** -0.5), rnd(N, seed=43), rnd(M, N, seed=44)
+    args = (x.to(dev).to(BF), w.to(dev), b.to(dev))
+    kw = dict(residual=r.to(dev).to(BF)) if res else {}
+    y = ops.linear(*args, row_stats=True, **kw)
+    y0 = ops.linear(*args, **kw)
+    assert torch.equal(y, y0)
+    st = getattr(y, "_crg_ln", None)
+    assert st is not None and st[1] == y._version and st[0].shape == (M, ops.row_stats_parts(N), 2)
+    s = st[0].double().sum(1).cpu()
+    yf = y.double().cpu()
+    assert (s[:, 0] - yf.sum(1)).abs().max().item() < 1e-4 * max(1.0, yf.abs().sum(1).max().item())
+    assert (s[:, 1] - (yf * yf).sum(1)).abs().max().item() < 1e-4 * (yf * yf).sum(1).max().item()
+    ops.axpby_(y, y0, 1.0, 1.0)  # a raw in-place write drops the side channel
+    assert getattr(y, "_crg_ln", None) is None
+
+
+@pytest.mark.parametrize("M,K,N,act,vt", [(8192, 640, 1920, None, True),      # Q | K | V of the 32x32 level, V third transposed (A)
+                                          (8192, 640, 640, None, False),      # to_q of the cross-attention (D)
+                                          (2048, 1280, 3840, None, True),     # 16x16 level (C)
+                                          (512, 1280, 1280, None, False),     # 8x8 level (C), few rows
+                                          (8192, 640, 5120, "geglu", False),  # GEGLU, 5 tiles per CU: the persistent ring kernel
+                                          (2048, 1280, 10240, "geglu", False),  # GEGLU, 2.5 tiles per CU: the LDS-DMA kernel (unpaired epilogue)
+                                          (4096, 1280, 3840, None, True),     # SDXL 32x32 level
+                                          (32768, 320, 960, None, True),      # K = 320 on the epilogue route (CRG_LN_EPI_320 = 2)
+                                          (32768, 320, 2560, "geglu", False)])
+@pytest.mark.parametrize("mean", [0.0, 6.0])
+def test_layernorm_as_gemm_epilogue(M, K, N, act, vt, mean, monkeypatch):
+    """nn.LayerNorm + Linear (attention.py:900-912) as ONE GEMM on the raw rows: the producer of x (a GEMM + residual of this library)
+    hands over row statistics, the consumer multiplies x by W o gamma and corrects in its epilogue (crg_gemm_args.ln_stats).  Against
+    LayerNorm in fp32 on the very bf16 rows the producer stored; rows with a mean of six standard deviations exercise the
+    cancellation mean * colsum; transposed V range, GEGLU (both kernels), every tile configuration."""
+    from cremage_amd import ops
+    monkeypatch.setattr(ops, "LN_EPI_320", 2)
+    dev = _dev()
+    T = 1024 if M % 1024 == 0 else M
+    B = M // T
+    x0, w0, r0 = rnd(B, T, K, seed=51), rnd(K, K, seed=52, scale=K ** -0.5), rnd(B, T, K, seed=53) + mean
+    x = ops.linear(x0.to(dev).to(BF), w0.to(dev), residual=r0.to(dev).to(BF), row_stats=True)  # the LayerNorm input, as to_out + residual writes it
+    assert getattr(x, "_crg_ln", None) is not None
+    g, be = 1.0 + 0.3 * rnd(K, seed=54), 0.2 * rnd(K, seed=55)
+    w, b = rnd(N, K, seed=56, scale=K ** -0.5), rnd(N, seed=57)
+    ln = torch.nn.LayerNorm(K).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(g)
+        ln.bias.copy_(be)
+    assert ops.ln_epi_ok(x, w.to(dev), act)
+    xr = x.float().cpu()
+    xhat = F.layer_norm(xr, (K,), None, None, ln.eps)
+    ref = F.linear(xhat, q(w * g, BF), w @ be + b)       # the function the kernel evaluates (W o gamma rounded once)
+    ref_plain = F.linear(F.layer_norm(xr, (K,), g, be, ln.eps), w, b)  # nn.LayerNorm + nn.Linear in fp32
+    if act == "geglu":
+        ref = ref[..., :N // 2] * F.gelu(ref[..., N // 2:])
+        ref_plain = ref_plain[..., :N // 2] * F.gelu(ref_plain[..., N // 2:])
+    n0 = 2 * (N // 3) if vt else None
+    got = ops.ln_linear_auto(x, ln, w.to(dev), b.to(dev), act=act, transposed_from=n0)
+    if vt:
+        qk, vt_ = got
+        got = torch.cat([qk, vt_[:, :, :T].transpose(1, 2)], dim=-1)
+    check(got, ref, BF, f"LN epilogue {M}x{N}x{K} {act}")
+    rel = ((got.float().cpu() - ref_plain).norm() / ref_plain.norm()).item()
+    assert rel < 8e-3, rel  # vs fp32 LayerNorm + Linear: bf16 rounding of W o gamma and of the output
+
+
 def test_linear_ring_gemm():
     """The persistent 256-row ring GEMM (gemm_ring.hip) against PyTorch in a child process that routes EVERY eligible shape to it
     (CRG_GEMM_RING=2, CRG_GEMM_RING_MIN=50: the knobs are read once per process; the default rule only takes GEGLU GEMMs with >= 3
