@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libcrg_hip.so")
 LIB_F16 = os.path.join(HERE, "libcrg_hip_f16.so")  # the same sources with -DCRG_F16_BUILD: fp16 operands (crg_common.h)
-SOURCES = ["crg_api.hip", "gemm_conv.hip", "conv_ring.hip", "conv_pp.hip", "gemm_ring.hip", "lngemm.hip", "norms.hip", "attention.hip", "small_ops.hip"]
+SOURCES = ["crg_api.hip", "gemm_conv.hip", "conv_pp.hip", "gemm_ring.hip", "lngemm.hip", "norms.hip", "attention.hip", "small_ops.hip"]
 HEADERS = [os.path.join(CSRC, "crg_common.h"), os.path.join(CSRC, "gemm_shared.h"), os.path.join(HERE, "..", "include", "crg_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 # attention.hip: without NaN-honouring semantics fmaxf lowers to plain v_max_f32 / v_max3_f32 instead of a canonicalising

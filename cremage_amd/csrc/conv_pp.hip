@@ -1,38 +1,23 @@
 // 3x3 / stride 1 / pad 1 conv on 256-pixel tiles with the two waves of every SIMD out of step (gfx950).
 //
-// Same math, operand layout, LDS images and DMA pieces as conv3_ring_kernel (conv_ring.hip): tile = 256 output pixels x BN
+// (Round 2's conv3_ring_kernel - the same tile, LDS images and DMA pieces with all eight waves in lockstep - was removed in round 4.)
+// Same math, operand layout and row-halo staging as conv3_rowhalo_kernel<.., MT = 2> (gemm_conv.hip); the pipeline:
+//   * the weight ring has FOUR slots: W(t + 3) is issued in k-tile t and only has to be in LDS at the top of k-tile t + 2;
+//   * the row buffer of group g + 1 (R x (W + 2) pixels of one 64-channel chunk and kernel row, shared by the three taps kw = 0..2) is
+//     issued whole in the first k-tile of group g (its slot was last read in group g - 1);
+//   * every wait is a counted s_waitcnt vmcnt(n) that leaves the newest issue batch in flight, followed by ONE raw s_barrier per
+//     k-tile; nothing in the loop drains to 0; every piece goes through a buffer descriptor whose range check supplies the zeros of
+//     the padding and of the tile tails.
+// LDS: 4 x BN x 128 B (80 KB at BN = 160) + 2 x <= 36 KB row buffers = 152 KB: one block per CU, two waves per SIMD.
+// Tile = 256 output pixels x BN
 // output channels on 8 waves (4 x 2, each 64 x 16 WNT), K in (64-channel chunk, kernel row) groups of three k-tiles that share
 // one row buffer, weight k-tiles through a 4-slot ring, everything by buffer_load ... lds behind counted s_waitcnt vmcnt(n).
-// Three schedules (template parameter SCHED), bitwise equal in their results (tests/test_hip_ops.py::test_conv_schedules):
-//   SCHED 1 (the default, CRG_RING = 6): the STAGGER - one barrier per k-tile, waves 0-3 multiply k-tile t and then read k-tile t + 1
-//            while waves 4-7 read k-tile t and then multiply it; described in front of its code further down.  8 % faster than the ring kernel.
-//   SCHED 2 (CRG_RING = 7): the stagger with the DMA pieces threaded between the MFMA groups - 3 % slower than SCHED 1.
-//   SCHED 0 (CRG_RING = 5): the 4-barrier PING-PONG described next - built first, as fast as the ring kernel, no faster (a barrier hand-off
-//            idles the matrix pipe for ~180 cycles); kept for the record and for the schedule-equivalence test.
-//
-// SCHED 0.  What is different is WHEN the two waves of a SIMD do what.  In the ring kernel all eight waves run the same stream between
-// the same barriers: both waves of a SIMD multiply together (and share the matrix pipe), then both read fragments and issue
-// their DMA pieces together (and the matrix pipe idles) - measured, the three costs ADD: 0.60 us of MFMAs + 0.25 us of LDS
-// reads + 0.19 us of DMA issue = the 1.0 - 1.1 us a k-tile takes.  Here a k-tile is two PHASES of
-//     load section (9 fragment reads of ONE 32-deep k-step, <= 3 DMA pieces, in phase b the counted wait for the next
-//     k-tile's operands) -> s_barrier -> 20 MFMAs -> s_barrier
-// and waves 4-7 run ONE BARRIER BEHIND waves 0-3 (they pass one extra barrier before the loop, waves 0-3 one after it), so that
-// between any two barriers one wave of every SIMD is in its MFMA cluster while its partner is in its load section
-// (cdna_hip_programming.md 5, the 8-phase template's stagger; MI355X_MICROARCH.md "Two waves per SIMD" items 5, 9).
-//
-// Hazards, in barrier EVENTS (event e = the e-th barrier release after the prologue's; waves 0-3 = group A pass a1 a2 b1 b2 of
-// k-tile t at events 4t .. 4t+3, waves 4-7 = group B at 4t+1 .. 4t+4):
-//   RAW  k-tile t is first read by A in its load section a(t), i.e. after event 4t-1.  Every wave waits (counted vmcnt) for its
-//        pieces of k-tile t at the end of ITS load section b(t-1), i.e. before its b1(t-1) = event 4t-2 (A) / 4t-1 (B).
-//   WAR  the last reads of k-tile t are B's in load section b(t); they have returned when B leaves its MFMA cluster b(t), i.e.
-//        at event 4t+4.  W(t+3) overwrites the slot of W(t-1) (free after event 4t): issued from load section b(t) on
-//        (A: after event 4t+1).  X(g+1) overwrites the buffer of X(g-1) (last k-tile 3g-1, free after event 12g): issued from
-//        load section b(3g) on.
-// DMA pieces per load section (per wave: nW = 2..3 weight pieces per k-tile, nX = 4..5 row-buffer pieces per group):
-//   a(t): W(t+2) pieces 1.. ; kw = 1 also X(g+1) piece 2       b(t): kw = 0: X(g+1) pieces 0, 1; kw = 1: X(g+1) pieces 3, 4;
-//                                                                     then W(t+3) piece 0
-// so that the wait at the end of b(t) leaves in flight  kw 0: nW + 3,  kw 1: nW + nX + 1,  kw 2: nW + 1  pieces (steady state).
-// One fragment set (36 VGPRs) instead of the ring kernel's two.  LDS as there: 4 x BN x 128 B + 2 row buffers.
+// The STAGGER: one barrier per k-tile, waves 0-3 multiply k-tile t and then read k-tile t + 1 while waves 4-7 read k-tile t and then
+// multiply it (described in front of its code further down): 8 % faster than the ring kernel, whose eight waves do each of the three
+// things in lockstep so that the three costs ADD (0.60 us of MFMAs + 0.25 us of LDS reads + 0.19 us of DMA issue = the 1.0 - 1.1 us of
+// a k-tile).  Two other schedules on the same tile were built and measured in round 3 and removed in round 4: a 4-barrier
+// ping-pong (load section -> barrier -> 20 MFMAs -> barrier, waves 4-7 one barrier behind: as fast as the ring kernel, no faster - a
+// barrier hand-off idles the matrix pipe for ~180 cycles) and the stagger with its DMA pieces threaded between the MFMA groups (3 % slower).
 #include "gemm_shared.h"
 #include <type_traits>
 
@@ -88,7 +73,7 @@ __device__ unsigned long long crg_pp_stamps[1024 * 8];
 
 }  // namespace
 
-template <int WNT, bool PAIR, bool LIN, int SCHED>
+template <int WNT, bool PAIR, bool LIN>
 __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(GemmP p) {
   constexpr int WMT = 4, NW = 8, TP = 256, WST = 4;
   constexpr int BN = 32 * WNT;
@@ -125,7 +110,7 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(GemmP p) {
   const int nW = (WRG - wave + NW - 1) / NW;
   const int nX = (XP - wave + NW - 1) / NW;
 
-  // per-lane source descriptors of the DMA pieces: see conv_ring.hip (same images)
+  // per-lane source descriptors of the DMA pieces (pixel index of the buffer position this lane fills + validity of its three kernel rows)
   constexpr int OOB = (int)0x80000000;
   int xp0[XI];
   unsigned xmask[XI];
@@ -244,8 +229,8 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(GemmP p) {
       const int u = xb0[j] + kw;
       xoff3[kw][j] = (u << 7) + (((u & 7) ^ fq) << 4);
     }
-  bf16x8 xf[WMT], wf[WNT];    // SCHED 0: the one fragment set; SCHED 1: k-step 0
-  bf16x8 xf1[WMT], wf1[WNT];  // SCHED 1: k-step 1
+  bf16x8 xf[WMT], wf[WNT];    // k-step 0
+  bf16x8 xf1[WMT], wf1[WNT];  // k-step 1
   auto read_x = [&](const char* xs, int kw, int ks) {
 #pragma unroll
     for (int j = 0; j < WMT; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xs + (xoff3[kw][j] ^ (ks << 6)));
@@ -336,121 +321,14 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(GemmP p) {
     }
   };
 
-  if constexpr (SCHED == 0) {
-  // One phase = one 32-deep k-step of k-tile tt (group g, tap column KW): load section -> barrier -> 20 MFMAs -> barrier.
-  // STEADY: a k-tile of a group that is not the slice's last (every scheduled piece exists: compile-time wait counts).
-  auto phase = [&](int g, int tt, auto KWc, auto KSc, auto STEADYc) {
-    constexpr int kw = decltype(KWc)::value;
-    constexpr int ks = decltype(KSc)::value;
-    constexpr bool STEADY = decltype(STEADYc)::value;
-    const char* xs = xbuf + ((g - g_begin) & 1) * xbuf_bytes;
-    const char* ws = wring + (tt & 3) * WS_BYTES;
-    const bool e_w2 = STEADY || tt + 2 < NT;
-    const bool e_w3 = STEADY || tt + 3 < NT;
-    const bool e_x = STEADY || g + 1 < g_end;
-    const bool last = !STEADY && kw == 2 && ks == 1;  // (the last k-tile of the slice is always a kw = 2 tile of the last group)
-    // ---- load section ----
-    read_x(xs, kw, ks);
-    read_w(ws, ks);
-    PP_SB;
-#ifndef CRG_ABL_NODMA
-    if constexpr (ks == 0) {
-      if (e_w2) {
-#pragma unroll
-        for (int q = 1; q < WL; ++q) w_piece(q, tt + 2);
-      }
-      if constexpr (kw == 1) {
-        if (e_x) { const XGroup xg = x_group(g + 1); x_piece(2, xg); }
-      }
-    } else {
-      if constexpr (kw == 0) {
-        if (e_x) { const XGroup xg = x_group(g + 1); x_piece(0, xg); x_piece(1, xg); }
-      } else if constexpr (kw == 1) {
-        if (e_x) { const XGroup xg = x_group(g + 1); x_piece(3, xg); x_piece(4, xg); }
-      }
-      if (e_w3) w_piece(0, tt + 3);
-    }
-#endif
-    if (last) fetch_res();
-    if constexpr (ks == 1) {
-      // everything k-tile tt + 1 reads has landed (pieces issued after it stay in flight)
-      if constexpr (STEADY) {
-        if constexpr (kw == 0) { if (nW == 3) wait_vmcnt<6>(); else wait_vmcnt<5>(); }
-        else if constexpr (kw == 1) {
-          if (nW == 3) { if (nX == 5) wait_vmcnt<9>(); else wait_vmcnt<8>(); }
-          else { if (nX == 5) wait_vmcnt<8>(); else wait_vmcnt<7>(); }
-        } else { if (nW == 3) wait_vmcnt<4>(); else wait_vmcnt<3>(); }
-      } else if (!last) {
-        int allow = (e_w2 ? nW : 0) + (e_w3 ? 1 : 0);
-        if (kw == 0) allow += e_x ? 2 : 0;
-        if (kw == 1) allow += e_x ? nX : 0;
-        pp_wait_vm_n(allow);
-      }
-    }
-    PP_BARRIER();
-    PP_SB;
-    if constexpr (LIN && kw != 1) {  // linear row buffer: a tap that would wrap around an image row contributes zeros
-#pragma unroll
-      for (int j = 0; j < WMT; ++j)
-        if ((edge >> (kw == 0 ? j : 8 + j)) & 1u) xf[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-#ifdef CRG_PP_PRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
-    mma();
-#ifdef CRG_PP_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-    PP_SB;
-    if (!last || !grp_b) PP_BARRIER();  // the slice's final phase: only waves 0-3 (they make up for the partners' extra barrier)
-  };
-
-  using std::integral_constant;
-  using K0 = integral_constant<int, 0>; using K1 = integral_constant<int, 1>; using K2 = integral_constant<int, 2>;
-  using T_ = integral_constant<bool, true>; using F_ = integral_constant<bool, false>;
-  if (NT > 0) {
-    // prologue: X(g0), W(0), W(1), piece 0 of W(2) (its other pieces follow in load section a(0), as in the steady state); the
-    // wait leaves W(1) and that piece in flight
-    {
-      const XGroup xg = x_group(g_begin);
-#pragma unroll
-      for (int i = 0; i < XI; ++i) x_piece(i, xg);
-    }
-#pragma unroll
-    for (int q = 0; q < WL; ++q) w_piece(q, 0);
-#pragma unroll
-    for (int q = 0; q < WL; ++q) w_piece(q, 1);  // NT >= 3
-    w_piece(0, 2);
-    pp_wait_vm_n(nW + 1);
-    PP_BARRIER();
-    if (grp_b) PP_BARRIER();  // the stagger: waves 4-7 run one barrier behind their SIMD partners from here on
-    int tt = 0;
-    for (int g = g_begin; g + 1 < g_end; ++g, tt += 3) {
-      phase(g, tt, K0{}, K0{}, T_{});
-      phase(g, tt, K0{}, K1{}, T_{});
-      phase(g, tt + 1, K1{}, K0{}, T_{});
-      phase(g, tt + 1, K1{}, K1{}, T_{});
-      phase(g, tt + 2, K2{}, K0{}, T_{});
-      phase(g, tt + 2, K2{}, K1{}, T_{});
-    }
-    phase(g_end - 1, tt, K0{}, K0{}, F_{});
-    phase(g_end - 1, tt, K0{}, K1{}, F_{});
-    phase(g_end - 1, tt + 1, K1{}, K0{}, F_{});
-    phase(g_end - 1, tt + 1, K1{}, K1{}, F_{});
-    phase(g_end - 1, tt + 2, K2{}, K0{}, F_{});
-    phase(g_end - 1, tt + 2, K2{}, K1{}, F_{});
-  } else {
-    fetch_res();
-  }
-  } else {
-  // ---- SCHED 1: the STAGGER (MI355X_MICROARCH.md "Two waves per SIMD" item 9) -------------------------------------------------
+  // ---- the STAGGER (MI355X_MICROARCH.md "Two waves per SIMD" item 9) -------------------------------------------------
   // One barrier per k-tile, as in the ring kernel, and the same issue / wait rule (interval t = between barriers t and t + 1:
   // W(t+3) and, in the first k-tile of a group, X(g+1) are issued; its end waits for everything issued BEFORE it), but the two
   // waves of a SIMD run half an interval apart with no barrier between the halves:
   //     waves 0-3:  barrier t | 40 MFMAs of k-tile t | issue | 18 fragment reads of k-tile t+1 | wait
   //     waves 4-7:  barrier t | 18 fragment reads of k-tile t | issue | 40 MFMAs of k-tile t   | wait
   // so one wave of every SIMD multiplies while its partner reads and issues, and the matrix pipe passes from one to the other
-  // without a barrier hand-off in between (the 4-barrier ping-pong above loses ~180 cycles of matrix pipe per hand-off).
+  // without a barrier hand-off in between (a 4-barrier ping-pong loses ~180 cycles of matrix pipe per hand-off).
   // Hazards: waves 0-3 read k-tile t+1 during interval t, so it has to be in LDS before barrier t: it was issued in interval
   // t-2 and the wait at the end of interval t-1 covers it.  W(t+3) overwrites the slot of W(t-1), last read (by waves 4-7) at
   // the start of interval t-1; X(g+1), issued in interval 3g, overwrites X(g-1), last read at the start of interval 3g-1.
@@ -489,52 +367,6 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(GemmP p) {
     mma();
     mma1();
   };
-  // SCHED 2: the interval's DMA pieces one at a time BETWEEN the MFMA groups (four MFMAs of one weight fragment each), so that a
-  // wave never sits in a burst of piece issues (the queue in front of the texture addresser is shared by the CU: a burst of four to
-  // eight pieces stalls the issuing wave for 100 - 185 cycles each, and in series with its MFMAs and fragment reads that burst is on
-  // the wave's critical path through the interval)
-  auto mma2_spread = [&](int g, int tt, auto KWc, bool on) {
-    constexpr int kw = decltype(KWc)::value;
-    if constexpr (LIN && kw != 1) {
-#pragma unroll
-      for (int j = 0; j < WMT; ++j)
-        if ((edge >> (kw == 0 ? j : 8 + j)) & 1u) { xf[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xf1[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
-    }
-    XGroup xg{};
-    if constexpr (kw == 0) { if (on) xg = x_group(g + 1); }
-    auto piece = [&](auto Kc) {  // slot k of the interval: row-buffer pieces first (first k-tile of a group), then the weight pieces
-      constexpr int k = decltype(Kc)::value;
-#ifndef CRG_ABL_NODMA
-      if (on) {
-        if constexpr (kw == 0) {
-          if constexpr (k < XI) x_piece(k, xg);
-          else if constexpr (k - XI < WL) w_piece(k - XI, tt + 3);
-        } else {
-          if constexpr (k < WL) w_piece(k, tt + 3);
-        }
-      }
-#endif
-    };
-    auto grp = [&](const bf16x8 (&x4)[WMT], const bf16x8& w1, auto Ic) {
-      constexpr int i = decltype(Ic)::value;
-#ifdef CRG_ABL_NOMMA
-      asm volatile("" ::"v"(w1));
-#pragma unroll
-      for (int j = 0; j < WMT; ++j) asm volatile("" ::"v"(x4[j]));
-#else
-#pragma unroll
-      for (int j = 0; j < WMT; ++j) acc[i][j] = CRG_MFMA_16x16x32(w1, x4[j], acc[i][j]);
-#endif
-    };
-    using std::integral_constant;
-#define PP_G(XA, WA, I, K) grp(XA, WA[I], integral_constant<int, I>{}); PP_SB; piece(integral_constant<int, K>{}); PP_SB;
-    PP_G(xf, wf, 0, 0) PP_G(xf, wf, 1, 1) PP_G(xf, wf, 2, 2) PP_G(xf, wf, 3, 3)
-    if constexpr (WNT > 4) { PP_G(xf, wf, 4, 4) }
-    PP_G(xf1, wf1, 0, 5) PP_G(xf1, wf1, 1, 6) PP_G(xf1, wf1, 2, 7) PP_G(xf1, wf1, 3, 8)
-    if constexpr (WNT > 4) { PP_G(xf1, wf1, 4, 9) }
-#undef PP_G
-    if constexpr (WNT <= 4) { piece(integral_constant<int, 4>{}); piece(integral_constant<int, 9>{}); }
-  };
   // wait at the end of interval tt: leaves in flight what the interval itself issued
   auto end_wait = [&](auto KWc, auto STEADYc) {
     constexpr int kw = decltype(KWc)::value;
@@ -562,16 +394,16 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(GemmP p) {
     if constexpr (GB) {
       reads(g, tt, KWc);
       PP_SB;
-      if constexpr (SCHED != 2) { if constexpr (STEADY) issue(g, tt, KWc, true, true); }
+      if constexpr (STEADY) issue(g, tt, KWc, true, true);
       if constexpr (LASTT) fetch_res();
       PP_SB;
-      if constexpr (SCHED == 2) mma2_spread(g, tt, KWc, STEADY); else mma2(KWc);
+      mma2(KWc);
       PP_SB;
       if constexpr (!LASTT) end_wait(KWc, STEADYc);
     } else {
-      if constexpr (SCHED == 2) mma2_spread(g, tt, KWc, STEADY); else mma2(KWc);
+      mma2(KWc);
       PP_SB;
-      if constexpr (SCHED != 2) { if constexpr (STEADY) issue(g, tt, KWc, true, true); }
+      if constexpr (STEADY) issue(g, tt, KWc, true, true);
       if constexpr (LASTT) fetch_res();
       if constexpr (!LASTT) {
         reads(kw == 2 ? g + 1 : g, tt + 1, KN{});
@@ -617,7 +449,6 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(GemmP p) {
   } else {
     fetch_res();
   }
-  }
   PP_STAMP(3);
   if constexpr (PAIR) {
     gemm_epilogue_pairs<WNT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, 0, r2, r1, pre_res, bpre, pre_bias);
@@ -635,21 +466,19 @@ extern "C" int crg_debug_read_pp(unsigned long long* dst, int n) {
 namespace crg_mm {
 #endif
 
-// Host entry (called from conv_ring.hip's launch_conv_ring when the ping-pong schedule is selected): bf16 in / bf16 out, no
-// in-launch split-K sum (p.inred launches stay on the ring kernel).
-int launch_conv_pp(crg_ctx* ctx, hipStream_t st, const GemmP& p, int wnt, int sched) {
+// Host entry (called from gemm_conv.hip's launch_kernel in place of the 2-stage 256-row kernel): bf16 in / bf16 out.
+int launch_conv_pp(crg_ctx* ctx, hipStream_t st, const GemmP& p, int wnt) {
   void (*kern)(GemmP) = nullptr;
   const bool lin = p.halo_lin != 0;
-#define CRG_PP_PICK(W, S) (p.pair ? (lin ? conv3_pp_kernel<W, true, true, S> : conv3_pp_kernel<W, true, false, S>) \
-                                  : (lin ? conv3_pp_kernel<W, false, true, S> : conv3_pp_kernel<W, false, false, S>))
-  if (wnt == 5) kern = sched == 2 ? CRG_PP_PICK(5, 2) : sched ? CRG_PP_PICK(5, 1) : CRG_PP_PICK(5, 0);
-  else if (wnt == 4) kern = sched == 2 ? CRG_PP_PICK(4, 2) : sched ? CRG_PP_PICK(4, 1) : CRG_PP_PICK(4, 0);
+#define CRG_PP_PICK(W) (p.pair ? (lin ? conv3_pp_kernel<W, true, true> : conv3_pp_kernel<W, true, false>) \
+                               : (lin ? conv3_pp_kernel<W, false, true> : conv3_pp_kernel<W, false, false>))
+  if (wnt == 5) kern = CRG_PP_PICK(5);
+  else if (wnt == 4) kern = CRG_PP_PICK(4);
   else return crg_fail(ctx, -22, "conv pp: unsupported tile width %d", wnt);
 #undef CRG_PP_PICK
   const int BN = 32 * wnt, TP = 256;
   const int XP = (p.halo_lin || p.Wo > TP) ? (TP + 2 + 7) / 8 : ((TP / p.Wo) * (p.Wo + 2) + 7) / 8;
   if (XP > 40) return crg_fail(ctx, -22, "conv pp: row buffer of %d pieces unsupported", XP);
-  if (p.inred) return crg_fail(ctx, -22, "conv pp: in-launch split-K sum unsupported");
   const size_t lds = (size_t)4 * BN * 128 + (size_t)2 * XP * 1024;
   if (int rc = crg_set_dyn_lds(ctx, reinterpret_cast<const void*>(kern), 160 * 1024, "conv pp")) return rc;
   hipLaunchKernelGGL(kern, dim3(p.tile_count * p.splits, 1, 1), dim3(512), lds, st, p);

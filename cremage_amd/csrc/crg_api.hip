@@ -59,11 +59,10 @@ extern "C" int crg_ctx_create(int device, crg_ctx** out) {
     hipDeviceProp_t prop;
     c->n_cu = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 0;
   }
-  if (hipMalloc(&c->zero_page, 4096 + 16384) != hipSuccess || hipMemset(c->zero_page, 0, 4096 + 16384) != hipSuccess) {
+  if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
     delete c;
     return -12;
   }
-  c->tile_cnt = reinterpret_cast<unsigned*>(static_cast<char*>(c->zero_page) + 4096);
   *out = c;
   return 0;
 }
@@ -91,8 +90,8 @@ extern "C" const char* crg_kernel_name(int slot) {
   static const char* const names[CRG_K_SLOTS] = {
       "gemm_glds_kernel<1, YT, false, STAGES, WMT, KG>", "gemm_glds_kernel<4, YT, false, STAGES, WMT, KG>",
       "gemm_glds_kernel<5, YT, false, STAGES, WMT, KG>", "gemm_kernel<WNT, NSPLIT, AT, YT, false, KG>",
-      "gemm_glds_kernel<1, YT, true, STAGES, WMT, KG>",  "conv3_ring_kernel<4, ...> | conv3_rowhalo_kernel<4, ...> | gemm_glds_kernel<4, YT, true, STAGES, WMT, KG>",
-      "conv3_pp_kernel<5, ...> | conv3_ring_kernel<5, ...> | conv3_rowhalo_kernel<5, ...> | gemm_glds_kernel<5, YT, true, STAGES, WMT, KG>", "conv3_rowhalo_kernel<WNT, float, false, 2, 2> | gemm_kernel<WNT, NSPLIT, AT, YT, true, KG>",
+      "gemm_glds_kernel<1, YT, true, STAGES, WMT, KG>",  "conv3_pp_kernel<4, ...> | conv3_rowhalo_kernel<4, ...> | gemm_glds_kernel<4, YT, true, STAGES, WMT, KG>",
+      "conv3_pp_kernel<5, ...> | conv3_rowhalo_kernel<5, ...> | gemm_glds_kernel<5, YT, true, STAGES, WMT, KG>", "conv3_rowhalo_kernel<WNT, float, false, 2, 2> | gemm_kernel<WNT, NSPLIT, AT, YT, true, KG>",
       "splitk_reduce_kernel<YT>", "attn_kernel<KS, NV>", "gn_stats_kernel<T>", "gn_apply_kernel<T> / gn_small_kernel<T, VPT>", "layernorm_kernel<T>",
       "elementwise (silu / axpby / affine_cast / transpose / timestep_embedding kernels)", "conv_small_*_kernel", "softmax_rows_kernel<T>",
       "lngemm_kernel<WNT, KT, PAIR>"};

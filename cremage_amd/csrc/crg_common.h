@@ -50,7 +50,6 @@ struct crg_ctx {
   size_t scratch_bytes = 0;
   std::vector<void*> retired;  // outgrown scratch buffers (kept alive: captured graphs / queued kernels may reference them)
   void* zero_page = nullptr;  // 4 KiB of zeros: LDS-DMA source for conv padding and tile tails
-  unsigned* tile_cnt = nullptr;  // 4096 split-K arrival counters (zero between launches: the last arriver resets its tile's), behind the zero page
   std::vector<const void*> lds_attr;  // kernels whose dynamic-LDS limit was raised ON THIS CONTEXT'S DEVICE (crg_set_dyn_lds)
   bool gn_fused = false;  // set by the split-K reduce launch when it also ran the GroupNorm behind the conv (crg_conv_args.gn_y)
   bool profiling = false;

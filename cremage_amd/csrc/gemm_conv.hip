@@ -1400,7 +1400,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(GemmP p) {
 // can the reduce behind this split-K launch also run the GroupNorm the caller asked for?
 template <typename YT>
 bool gn_slab_ok(const GemmP& p, int batch) {
-  if (sizeof(YT) != 2 || !p.gn_y || !p.gn_gamma || !p.gn_beta || batch != 1 || p.slab_row0 != 0 || p.inred || p.gstat || p.vt) return false;
+  if (sizeof(YT) != 2 || !p.gn_y || !p.gn_gamma || !p.gn_beta || batch != 1 || p.slab_row0 != 0 || p.gstat || p.vt || p.rstat) return false;
   if (p.epi != CRG_EPI_NONE || (p.bias_mode != CRG_BIAS_NONE && p.bias_mode != CRG_BIAS_COL)) return false;
   if (p.gn_groups <= 0 || p.N % p.gn_groups || p.gn_hw <= 0 || p.M % p.gn_hw || p.ldy != p.N) return false;
   const int gs = p.N / p.gn_groups;
@@ -1489,13 +1489,11 @@ struct Work {  // algorithmic work of one call (profiler) and operand footprints
 };
 
 // (xg_m, xg_n, xg_s): see block_to_tile.  Minimise fabric traffic xg_n*|A| + xg_m*|W| over the feasible factorizations of 8.
-// same_xcd: keep all K slices of a tile on one XCD (the in-kernel reducer then reads its partners' slabs through the shared L2)
-inline void choose_xcd_partition(GemmP& p, const Work& wk, bool same_xcd = false) {
-  static const int knob = getenv("CRG_INRED_XS") ? atoi(getenv("CRG_INRED_XS")) : 1;
+inline void choose_xcd_partition(GemmP& p, const Work& wk) {
   p.xg_m = p.xg_n = 1;
   p.xg_s = 0;
   double best = 0.0;
-  for (int gs = (same_xcd && knob) ? 1 : 8; gs >= 1; gs >>= 1) {
+  for (int gs = 8; gs >= 1; gs >>= 1) {
     if (p.splits % gs) continue;
     for (int gn = 1; gn * gs <= 8; gn <<= 1) {
       const int gm = 8 / (gs * gn);
@@ -1519,16 +1517,16 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     p.ks_q = nk_total / p.splits;
     p.ks_r = nk_total % p.splits;
   }
-  p.pair = (GLDS && sizeof(YT) == 2 && (p.splits == 1 || p.inred) && p.epi != CRG_EPI_GEGLU && (p.N & 7) == 0 && (p.ldy & 7) == 0 &&
+  p.pair = (GLDS && sizeof(YT) == 2 && p.splits == 1 && p.epi != CRG_EPI_GEGLU && (p.N & 7) == 0 && (p.ldy & 7) == 0 &&
             (p.y_bs & 7) == 0 && ((uintptr_t)p.y & 15) == 0 &&
             (!p.res || ((p.ldr & 7) == 0 && (p.r_bs & 7) == 0 && ((uintptr_t)p.res & 15) == 0)) &&
             (!p.cvec || (p.cvec_ld & 3) == 0)) ? 1 : 0;
   if (p.vt && !(p.pair && p.splits == 1 && !p.gstat && !CONV))
     return crg_fail(ctx, -22, "gemm: a transposed column range needs the paired bf16 epilogue of an unsplit, unbatched GEMM (N, ldy multiples of 8, K below the split-K rule)");
-  if (p.gstat && !p.pair && (p.splits == 1 || p.inred))
+  if (p.gstat && !p.pair && p.splits == 1)
     return crg_fail(ctx, -22, "gemm/conv: GroupNorm statistics come from the paired bf16 epilogue (N, ldy, ldr multiples of 8, 16-byte aligned y / residual, no GEGLU)");
   if (p.rstat && !(!p.gstat && !p.vt && !CONV && batch == 1 && sizeof(YT) == 2 && p.rstat_parts == 2 * p.tiles_n && p.epi == CRG_EPI_NONE &&
-                   ((p.splits == 1 && p.pair) || (p.splits > 1 && !p.inred && (p.N & 3) == 0 && (p.ldy & 3) == 0 && (!p.res || (p.ldr & 3) == 0)))))
+                   ((p.splits == 1 && p.pair) || (p.splits > 1 && (p.N & 3) == 0 && (p.ldy & 3) == 0 && (!p.res || (p.ldr & 3) == 0)))))
     return crg_fail(ctx, -22, "gemm: LayerNorm row statistics come from the paired bf16 epilogue of an unbatched plain GEMM (N, ldy multiples of 8) or from its split-K reduce, with row_stats_parts = 2 * ceil(N / tile) = %d (got %d)", 2 * p.tiles_n, p.rstat_parts);
   if (p.ln_stat && !(GLDS && sizeof(YT) == 2 && !CONV && p.splits == 1 && batch == 1 && !p.res && !p.gstat && !p.rstat && !p.cvec && (p.N & 3) == 0 &&
                      (p.bias_mode == CRG_BIAS_COL || p.bias_mode == CRG_BIAS_NONE) && (p.epi == CRG_EPI_NONE || p.epi == CRG_EPI_GEGLU)))
@@ -1576,7 +1574,7 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
                                      : (WNT == 5 ? CRG_K_GEMM_W5 : WNT == 4 ? CRG_K_GEMM_W4 : CRG_K_GEMM_W1));
   crg_prof_scope ps(ctx, st, slot, wk.flops, wk.bytes);
   if constexpr (GLDS && CONV && STAGES == 2 && WMT == 4 && KG == 1 && sizeof(YT) == 2 && (WNT == 4 || WNT == 5)) {
-    if (halo && p.rowhalo == 2 && p.ring) return launch_conv_ring(ctx, st, p, WNT, p.ring - 1);
+    if (halo && p.rowhalo == 2 && p.ring) return launch_conv_pp(ctx, st, p, WNT);
   }
   hipLaunchKernelGGL(kern, grid, dim3(threads), lds_bytes, st, p);
   CRG_CHECK_LAUNCH(ctx, "gemm");
@@ -1639,26 +1637,17 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
       }
     }
   }
-  p.ring = p.inred = 0;
+  p.ring = 0;
   if constexpr (GLDS && CONV && sizeof(YT) == 2 && (WNT == 4 || WNT == 5)) {
-    // deep-ring kernel (conv_ring.hip) for the 256-row configuration; with 2..4 K slices it also sums them itself (last arriver)
-    static const int ring = getenv("CRG_RING") ? atoi(getenv("CRG_RING")) : 6;      // dev knob: 0 = 2-stage 256-row kernel, 1 / 2 = ring kernel (DMA issue at the top / behind the first MFMA block), 5 = 4-barrier ping-pong, 6 (default) = staggered waves (conv_pp.hip)
-    static const int inred = getenv("CRG_INRED") ? atoi(getenv("CRG_INRED")) : 0;   // dev knob: most K slices summed in-kernel.  Default 0 = always the reduce kernel: measured SLOWER in-kernel (8x32x32 640->640 72.0 -> 78.7 us, 8x16x16 1280->1280 69.1 -> 76.4 us: 160 KB of fp32 per slice and tile is far past the few tens of KB where the guide says an in-launch seam pays)
-    if (p.rowhalo == 2 && ring && p.a_bytes && p.w_bytes && (p.C2 == 0 || p.x2_bytes) && (long)p.M / (p.Ho * p.Wo) * p.H * p.W < (1 << 24)) {
-      p.ring = ring;
-      if (p.splits > 1 && p.splits <= inred && p.tiles_m * p.tiles_n <= 2048 && (p.N & 3) == 0) {
-        p.inred = 1;
-        p.tile_cnt = ctx->tile_cnt;
-      }
-    }
+    // the staggered-wave kernel (conv_pp.hip) for the 256-row configuration, where its buffer descriptors can address the operands
+    if (p.rowhalo == 2 && p.a_bytes && p.w_bytes && (p.C2 == 0 || p.x2_bytes) && (long)p.M / (p.Ho * p.Wo) * p.H * p.W < (1 << 24)) p.ring = 1;
   }
   if (p.splits > 1) {
-    const size_t bytes = p.inred ? (size_t)p.tiles_m * p.tiles_n * p.splits * 256 * BN * sizeof(float)
-                                 : (size_t)batch * p.splits * p.M * p.N * sizeof(float);
+    const size_t bytes = (size_t)batch * p.splits * p.M * p.N * sizeof(float);
     p.slab = (float*)crg_scratch(ctx, bytes);
     if (!p.slab) return crg_fail(ctx, -12, "gemm: out of scratch for %d split-K slabs", p.splits);
   }
-  choose_xcd_partition(p, wk, p.inred != 0);
+  choose_xcd_partition(p, wk);
   p.tile_base = 0;
   p.tile_count = p.tiles_n * p.tiles_m;
   p.slab_row0 = 0;
@@ -1704,7 +1693,7 @@ int launch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     rc = launch_kernel<WNT, NSPLIT, AT, YT, CONV, 2, 4, 1>(ctx, st, p, batch, wk);
   }
   if (rc) return rc;
-  if (p.splits > 1 && !p.inred) return launch_reduce<YT>(ctx, st, p, batch);
+  if (p.splits > 1) return launch_reduce<YT>(ctx, st, p, batch);
   return 0;
 }
 

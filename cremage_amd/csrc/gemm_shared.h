@@ -1,4 +1,4 @@
-// Shared pieces of the MFMA GEMM / implicit-GEMM conv kernels (gemm_conv.hip, conv_ring.hip): problem descriptor,
+// Shared pieces of the MFMA GEMM / implicit-GEMM conv kernels (gemm_conv.hip, conv_pp.hip, gemm_ring.hip): problem descriptor,
 // block -> tile mapping, LDS swizzle, epilogues, counted vmcnt wait.
 #pragma once
 #include "crg_common.h"
@@ -29,10 +29,8 @@ struct GemmP {
   int rowhalo;     // conv: eligible for conv3_rowhalo_kernel (3x3, stride 1, pad 1, chunk-major K); 2 = on 256-row tiles
   int halo_lin;    // ... with the linear-pixel row buffer (widths that neither divide the tile nor are a multiple of it)
   int ks_q, ks_r;  // k-tiles per K-slice: nk_total = splits * ks_q + ks_r
-  int ring;             // conv: runs on conv3_ring_kernel (conv_ring.hip)
-  int inred;            // ... which sums its K slices itself: slab = register images [tile][slice][wave][i][j][lane] f32x4,
-  unsigned* tile_cnt;   //     arrival counter per tile (zero on entry, reset by the last arriver)
-  unsigned a_bytes, x2_bytes, w_bytes;  // conv: byte sizes of x, x2 and the packed weight (buffer descriptors of conv_ring.hip); 0 = unknown / >= 2 GiB
+  int ring;             // conv: runs on conv3_pp_kernel (conv_pp.hip: 256-pixel tiles, staggered waves)
+  unsigned a_bytes, x2_bytes, w_bytes;  // conv: byte sizes of x, x2 and the packed weight (buffer descriptors of conv_pp.hip); 0 = unknown / >= 2 GiB
   int xg_m, xg_n, xg_s;  // XCD partition of the (m-tile, n-tile, k-slice) grid, product 8; xg_s == 0: legacy contiguous order
   // GroupNorm statistics side channel (crg_*_args.gn_stats): per 32-row block and output channel, the sum and the sum of squares of
   // the FINISHED (bf16-rounded) outputs: gstat[0][rb][n] / gstat[1][rb][n], plane stride gstat_plane floats.  Written by the paired
@@ -110,7 +108,7 @@ template <int WNT, typename YT, int WMT = 4>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[WNT][WMT], int m0, int n0, int wm, int wn, int frow, int fq,
                                               int bz, int sid, const bf16x4 (&pre)[WNT][WMT], bool use_pre,
                                               const f32x4 (&bpre)[WNT], bool use_bpre) {
-  if (p.splits > 1 && !p.inred) {
+  if (p.splits > 1) {
     const long srows = p.M - p.slab_row0;
     float* S = p.slab + ((long)bz * p.splits + sid) * srows * p.N - (long)p.slab_row0 * p.N;
 #pragma unroll
@@ -487,10 +485,9 @@ __device__ __forceinline__ void wait_vmcnt() {  // s_waitcnt vmcnt(N) only (expc
   __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
 }
 
-// conv_ring.hip: deep-ring 256-pixel-tile 3x3 conv (bf16), launched in place of conv3_rowhalo_kernel<.., MT = 2>
-int launch_conv_ring(crg_ctx* ctx, hipStream_t st, const GemmP& p, int wnt, int spread);
-// conv_pp.hip: the same tile and LDS images on the ping-pong schedule (waves 4-7 one barrier behind waves 0-3); spread == 4 / 5 above
-int launch_conv_pp(crg_ctx* ctx, hipStream_t st, const GemmP& p, int wnt, int sched);  // sched 0: 4-barrier ping-pong, 1: stagger
+// conv_pp.hip: 3x3 / stride 1 conv on 256-pixel tiles, 4-slot weight ring + halo'd row buffers, the two waves of a SIMD half a k-tile
+// apart (bf16), launched in place of conv3_rowhalo_kernel<.., MT = 2>
+int launch_conv_pp(crg_ctx* ctx, hipStream_t st, const GemmP& p, int wnt);
 // gemm_ring.hip: persistent 256-row-tile GEMM (bf16, plain / GEGLU epilogue), launched in place of gemm_glds_kernel where it applies
 bool ring_gemm_ok(const GemmP& p, int batch, int n_cu);
 int launch_gemm_ring(crg_ctx* ctx, hipStream_t st, const GemmP& p, double flops, double bytes);

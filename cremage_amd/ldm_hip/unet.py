@@ -133,13 +133,8 @@ class ResBlock(TimestepBlock):
         if emb_out is None:
             emb_out = self.emb_layers[1](ops.silu(emb), out_dtype=torch.float32)  # [N, Cout] fp32
         h = self.in_layers[0](x, silu=True, x2=x2)                              # GN32 + SiLU (one tensor even for a pair)
-        gn = self.out_layers[0]
-        if ops.conv_gn_fusable(h.shape[2] * h.shape[3], h.dtype) and self.in_layers[2].kernel_size == (3, 3) and gn.num_channels % (8 * gn.num_groups) == 0:
-            # 8x8 / 16x16 levels: conv + bias + emb_out and the GroupNorm + SiLU behind it in ONE call (the split-K reduce normalises)
-            _, h = self.in_layers[2](h, cvec=emb_out, gn=(gn.weight, gn.bias, gn.num_groups, gn.eps, True))
-        else:
-            h = self.in_layers[2](h, cvec=emb_out, gn_stats=True)               # conv + bias + emb_out[:, :, None, None]; statistics for out_layers[0]
-            h = gn(h, silu=True)
+        h = self.in_layers[2](h, cvec=emb_out, gn_stats=True)                   # conv + bias + emb_out[:, :, None, None]; statistics for out_layers[0]
+        h = self.out_layers[0](h, silu=True)
         if isinstance(self.skip_connection, nn.Identity):
             skip = x if x2 is None else torch.cat([x, x2], dim=1)
         else:

@@ -179,6 +179,7 @@ LN_EPI = _env.get("CRG_LN_EPI", "1") != "0"          # dev knob (A/B): 0 = stand
 # projections on the epilogue route (device time in a graph, tools/lnepi_probe.py: LN + Q | K | V 43.4 -> 40.6 us, LN + to_q 19.1 -> 16.6),
 # the GEGLU projection stays row-resident (76.8 us against 95.7 on the epilogue route), 2 = the GEGLU projection as well
 LN_EPI_320 = int(_env.get("CRG_LN_EPI_320", "1"))
+LN_EPI_MASK = int(_env.get("CRG_LN_EPI_MASK", "3"))   # dev knob (A/B): bit 0 = plain consumers (Q | K | V, to_q) on the epilogue route, bit 1 = GEGLU consumers
 
 
 def row_stats_parts(n: int) -> int:
@@ -190,7 +191,7 @@ def row_stats_parts(n: int) -> int:
 def ln_epi_wanted(width: int, geglu: bool = False) -> bool:
     """Should the producer of a LayerNorm input of this width emit row statistics - would its consumer (the GEGLU projection if `geglu`,
     else a plain projection) use them?"""
-    return LN_EPI and row_stats_parts(width) <= 16 and (width != 320 or LN_EPI_320 >= (2 if geglu else 1))
+    return LN_EPI and bool(LN_EPI_MASK & (2 if geglu else 1)) and row_stats_parts(width) <= 16 and (width != 320 or LN_EPI_320 >= (2 if geglu else 1))
 
 
 def _ln_stats_of(x: torch.Tensor) -> Optional[torch.Tensor]:
@@ -203,7 +204,7 @@ def _ln_stats_of(x: torch.Tensor) -> Optional[torch.Tensor]:
 
 def ln_epi_ok(x: torch.Tensor, weight: torch.Tensor, act: Optional[str] = None) -> bool:
     """Can `linear(x, weight, ..., ln=...)` run - does x carry valid row statistics and does the GEMM take the shape?"""
-    if not (LN_EPI and x.is_cuda and x.dtype == HALF and x.is_contiguous() and act in (None, "geglu")):
+    if not (LN_EPI and x.is_cuda and x.dtype == HALF and x.is_contiguous() and act in (None, "geglu")) or not (LN_EPI_MASK & (2 if act == "geglu" else 1)):
         return False
     K = x.shape[-1]
     M = x.numel() // K
@@ -758,19 +759,6 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if stats is not None:
         y._crg_gn = (stats, y._version, ho * wo)
     return y if gn is None else (y, y_norm)
-
-
-def conv_gn_fusable(hw: int, dtype) -> bool:
-    """Is conv2d(..., gn=...) worth asking for?  Only where the GroupNorm would otherwise be the single-launch kernel (images below
-    GN_STATS_MIN_HW pixels, bf16): larger images take the statistics side channel + apply pair, which the fused form cannot beat."""
-    return CONV_GN and dtype == HALF and hw < GN_STATS_MIN_HW
-
-
-# dev knob: 1 = ResBlocks of the 8x8 / 16x16 levels ask for conv + GroupNorm in one call.  Default 0: measured equal-to-slower in the
-# bench (227.8 -> 228.3 ms, two alternating pairs in one gpurun call): the fused launch reads its (sample, group) slab of the fp32 K slices
-# in 160-byte row segments and takes as long as the coalesced reduce plus the single-launch GroupNorm it replaces (split-K reduce
-# +2.1 ms, GroupNorm -1.9 ms per batch); the saved launch does not pay for the access shape.
-CONV_GN = __import__("os").environ.get("CRG_CONV_GN", "0") != "0"
 
 
 def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias=None, residual: Optional[torch.Tensor] = None, gn_stats: bool = False) -> torch.Tensor:

@@ -93,13 +93,35 @@ def decode_images(ldm: LatentDiffusion, samples: torch.Tensor, batch_decode: boo
 
 
 @torch.no_grad()
+def trajectory_noise_sampler(steps: int, shape, device, generators=None) -> Callable:
+    """Ancestral noise of a whole sampling run drawn UP FRONT - one randn per image generator (or one for the batch from the default
+    generator) instead of one per image and step - and handed out step by step: the same number of Gaussian samples as the per-step
+    `torch.randn_like(x)` of k-diffusion's default noise sampler (sampling.py:147-163), in 1 / b launches instead of `steps` / b * steps.
+    The last step of a schedule that ends at sigma = 0 draws nothing, as in the reference."""
+    if generators is not None:
+        noise = torch.stack([torch.randn((steps,) + tuple(shape[1:]), generator=g, device=device) for g in generators], dim=1)
+    else:
+        noise = torch.randn((steps,) + tuple(shape), device=device)
+    it = iter(range(steps))
+    return lambda sigma, sigma_next: noise[next(it)]
+
+
+@torch.no_grad()
 def txt2img(ldm: LatentDiffusion, c: torch.Tensor, uc: Optional[torch.Tensor], *, steps: int = 20, sampler: str = "euler_a",
             cfg_scale: float = 7.5, height: int = 512, width: int = 512, x0: Optional[torch.Tensor] = None,
-            noise_sampler: Optional[Callable] = None, decode: bool = True, hint: Optional[torch.Tensor] = None):
+            noise_sampler: Optional[Callable] = None, decode: bool = True, hint: Optional[torch.Tensor] = None, generators=None):
     """Returns (images or None, final latents).  `hint` ([b,3,H,W] in [0,1], ControlLDM only): the ControlNet control image;
     conditioning becomes {"c_crossattn": [c], "c_concat": [hint]} for both the positive and the negative prompt
-    (image_generator.py:795-808)."""
+    (image_generator.py:795-808).  `generators`: one torch.Generator per image (seed + global image index, cremage_amd.dist.image_seed):
+    the initial latents (unless x0 is given) and the ancestral noise of image i come from generators[i], so that a batch sharded over
+    GPUs draws what the unsharded batch draws.  Without an explicit `noise_sampler` the ancestral sampler's noise is drawn once per run
+    (trajectory_noise_sampler)."""
     b = c.shape[0]
+    dev = c.device
+    if x0 is None and generators is not None:
+        x0 = torch.stack([torch.randn((4, height // 8, width // 8), generator=g, device=dev) for g in generators])
+    if noise_sampler is None and sampler == "euler_a" and dev.type == "cuda":
+        noise_sampler = trajectory_noise_sampler(steps, (b, 4, height // 8, width // 8), dev, generators)
     if hint is not None:
         c = {"c_crossattn": [c], "c_concat": [hint]}
         uc = {"c_crossattn": [uc], "c_concat": [hint]} if uc is not None else None

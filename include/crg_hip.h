@@ -70,7 +70,7 @@ int crg_ctx_reserve(crg_ctx* ctx, size_t bytes);
 enum crg_kernel_slot {
   CRG_K_GEMM_W1 = 0, CRG_K_GEMM_W4 = 1, CRG_K_GEMM_W5 = 2, /* gemm_glds_kernel<WNT, *, CONV=false>  bf16 LDS-DMA GEMM      */
   CRG_K_GEMM_X3 = 3,                                        /* gemm_kernel<*, *, *, *, false>        fp32 / split-bf16 GEMM */
-  CRG_K_CONV_W1 = 4, CRG_K_CONV_W4 = 5, CRG_K_CONV_W5 = 6, /* conv3_ring_kernel<WNT> / conv3_rowhalo_kernel<WNT> / gemm_glds_kernel<WNT, *, CONV=true>  bf16 implicit-GEMM conv */
+  CRG_K_CONV_W1 = 4, CRG_K_CONV_W4 = 5, CRG_K_CONV_W5 = 6, /* conv3_pp_kernel<WNT> / conv3_rowhalo_kernel<WNT> / gemm_glds_kernel<WNT, *, CONV=true>  bf16 implicit-GEMM conv */
   CRG_K_CONV_X3 = 7,                                        /* gemm_kernel<*, *, *, *, true>         fp32-class conv (VAE)  */
   CRG_K_SPLITK = 8, CRG_K_ATTN = 9, CRG_K_GN_STATS = 10, CRG_K_GN_APPLY = 11, CRG_K_LAYERNORM = 12,
   CRG_K_ELEMENTWISE = 13, CRG_K_CONV_SMALL = 14, CRG_K_SOFTMAX = 15,

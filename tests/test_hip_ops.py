@@ -440,9 +440,9 @@ def test_conv_rowhalo_shapes(N, C1, C2, H, W, Co):
     (2, 128, 0, 128, 128, 320, False),  # W = 128 divides the tile: two image rows per tile
     (1, 128, 0, 64, 512, 320, False),   # W = 512 > tile: one 256-pixel row SEGMENT per tile
 ])
-def test_conv_ring_shapes(N, C1, C2, H, W, Co, up):
-    """3x3 convs whose grid fills rounds of 256-pixel tiles run on conv3_ring_kernel (conv_ring.hip: 4-slot weight ring,
-    counted vmcnt, cross-k-tile fragment prefetch): every buffer geometry, split-K, concat, upsample and epilogue term."""
+def test_conv_256_pixel_tile_shapes(N, C1, C2, H, W, Co, up):
+    """3x3 convs whose grid fills rounds of 256-pixel tiles run on conv3_pp_kernel (conv_pp.hip: 4-slot weight ring, counted vmcnt,
+    the two waves of a SIMD half a k-tile apart): every buffer geometry, split-K, concat, upsample and epilogue term."""
     from cremage_amd import ops
     C = C1 + C2
     x = rnd(N, C1, H, W, seed=180)
@@ -490,29 +490,6 @@ def test_conv_gn_fused(N, C1, C2, H, W, Co, res):
     check(y, ref, BF, "conv_gn raw")
     refn = F.silu(F.group_norm(y2.float().cpu(), 32, g.cpu(), be.cpu(), 1e-5))
     check(yn, refn, BF, "conv_gn normalised")
-
-
-def test_conv_schedules():
-    """The 256-pixel-tile 3x3 conv under every schedule the library carries, each in a child process (CRG_RING is read once per
-    process): 6 = staggered waves (conv_pp.hip, the default), 7 = the same with the DMA pieces threaded between the MFMA groups, 5 = the 4-barrier ping-pong form, 2 = the deep-ring kernel of round 2
-    (conv_ring.hip), 0 = the 2-stage 256-row row-halo kernel.  All of them accumulate every output in the same order (same tile,
-    same K slices, same split-K reduce), so beyond matching the fp32 reference they must agree BITWISE with each other."""
-    import json
-    import os
-    import subprocess
-    import sys
-    from tests.conftest import REPO
-    results = {}
-    for ring in ("6", "7", "5", "2", "0"):
-        env = dict(os.environ, CRG_RING=ring)
-        r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_conv_sched_run.py")], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, (ring, r.stderr[-3000:])
-        results[ring] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("CONV_SCHED_RESULT ")][-1][len("CONV_SCHED_RESULT "):])
-    assert len(results["6"]) == 11
-    for ring, res in results.items():
-        for case, (rel, digest) in res.items():
-            assert rel < 6e-3, (ring, case, rel)
-            assert digest == results["6"][case][1], f"CRG_RING={ring} differs from the default schedule on {case}"
 
 
 @pytest.mark.parametrize("N,C,H,W,Co", [(2, 64, 8, 8, 64), (1, 128, 16, 32, 160), (1, 64, 3, 64, 64), (1, 64, 2, 128, 64), (2, 64, 5, 12, 96)])
