@@ -112,6 +112,7 @@ struct RingP {
   int M, N, K, nk;
   int tiles_m, tiles_n, tile_count;
   int xg_m, xg_n;                              // XCD partition of the (m-tile, n-tile) grid (product 8) or 0: contiguous runs
+  int st_m, st_n;                              // supertile of the blocks co-resident on one XCD (st_m * st_n = grid / 8), see rg_tile; 0 = n-fastest order
   // LayerNorm as an epilogue correction (GemmP::ln_stat): y = rstd_m * (acc - mean_m * ln_s[n]) + bias'[n] on the raw rows
   const float* ln_stat; int ln_parts; const float* ln_s; float ln_eps;
 };
@@ -123,7 +124,21 @@ static __device__ __forceinline__ void rg_tile(const RingP& p, int L, int& tile_
     const int xcd = L & 7, idx = L >> 3;
     const int xn = xcd % p.xg_n, xm = xcd / p.xg_n;
     const int nnl = p.tiles_n / p.xg_n, nml = p.tiles_m / p.xg_m;
-    const int tn = idx % nnl, tm = idx / nnl;
+    int tn, tm;
+    if (p.st_m) {
+      // The grid / 8 blocks an XCD hosts at a time work on ONE st_m x st_n supertile (m fastest inside it), and the supertiles follow
+      // each other along n: the st_m row blocks of A stay in the XCD's L2 for the whole n sweep and every weight panel is fetched once
+      // per supertile row.  (n-fastest over the whole share - round 3 - kept only two row blocks in flight and walked ALL the share's
+      // weight panels for them, 20 tiles' worth of W per pair of row blocks, while the output stream evicted them: PMC FETCH_SIZE
+      // 147 MB per launch against 17 MB of operands at 8192 x 5120 x 640.)
+      const int per = p.st_m * p.st_n, q = idx / per, r = idx - q * per;
+      const int nsn = nnl / p.st_n, ms = q / nsn, ns = q - ms * nsn;
+      tm = ms * p.st_m + r % p.st_m;
+      tn = ns * p.st_n + r / p.st_m;
+    } else {
+      tn = idx % nnl;
+      tm = idx / nnl;
+    }
     tile_n = xn * nnl + tn;
     tile_m = xm * nml + tm;
   } else {
@@ -505,6 +520,25 @@ int launch_gemm_ring(crg_ctx* ctx, hipStream_t st, const GemmP& g, double flops,
   int grid = ctx->n_cu > 0 ? ctx->n_cu : 256;
   grid &= ~7;  // a block's tile ids must stay on one XCD label
   if (grid > p.tile_count) grid = p.tile_count;
+  p.st_m = p.st_n = 0;
+  {
+    static const int super = getenv("CRG_GEMM_RING_SUPER") ? atoi(getenv("CRG_GEMM_RING_SUPER")) : 1;  // dev knob (A/B): 0 = n-fastest tile order inside an XCD's share
+    const int per = grid / 8;  // blocks of one XCD, i.e. tiles it works on at a time
+    if (super && p.xg_m && grid % 8 == 0 && per > 0) {
+      const int nnl = p.tiles_n / p.xg_n, nml = p.tiles_m / p.xg_m;
+      // ... where the XCD's whole row share is ONE supertile row (its A rows then stay in L2 for the entire launch).  Measured, device time in
+      // a graph + PMC (tools/ring_pmc.sh, round 4): 8192 x 5120 x 640 FETCH_SIZE 147 -> 87 MB per launch, 86.7 -> 82.4 us; 4096 x 10240 x 1280
+      // 144.3 -> 141.5 us; with two supertile rows per XCD (16384 x 5120 x 640) 158.7 -> 161.2 us, with sixteen (K = 320) +4 %: those keep
+      // the n-fastest order
+      for (int sm = 8; sm >= 1; sm >>= 1) {
+        if (per % sm || nml != sm) continue;
+        const int sn = per / sm;
+        if (nnl % sn) continue;
+        p.st_m = sm; p.st_n = sn;
+        break;
+      }
+    }
+  }
   static const int stag = getenv("CRG_GEMM_RING_STAG") ? atoi(getenv("CRG_GEMM_RING_STAG")) : 1;  // dev knob: 0 = all eight waves in lockstep (round 3a)
   void (*kern)(RingP) = stag ? (geglu ? gemm_ring_kernel<4, true> : (wnt == 5 ? gemm_ring_kernel<5, false> : gemm_ring_kernel<4, false>))
                              : (geglu ? gemm_ring_kernel<4, true, false> : (wnt == 5 ? gemm_ring_kernel<5, false, false> : gemm_ring_kernel<4, false, false>));
