@@ -199,20 +199,20 @@ def main():
 # End-to-end error of each UNet operand type against the fp32 CPU reference: full-size C1 (SD1.5 512x512, 20-step Euler, CFG 7.5, one
 # image; reference-run fixture traj_c1_sd15_full.npz), measured on MI355X and bounded at 1.5x by tests/test_hip_models.py
 # (test_c1_sd15_full_20_step_trajectory, test_fp16_operand_build, test_vae_sd15_full_decode_pixels).  Pixels in [-1, 1].
-PARITY = {
-    "bf16": {"c1_latent_rel_l2": 6.5e-2, "c1_pixel_linf": 0.133, "c1_pixel_mean_abs": 1.5e-2},
-    "f16": {"c1_latent_rel_l2": 8.1e-3, "c1_pixel_linf": 1.5e-2, "c1_pixel_mean_abs": 1.9e-3},
-    "fp32": {"c1_latent_rel_l2": 9.0e-5, "c1_pixel_linf": 2.7e-4, "c1_pixel_mean_abs": None},
+PARITY = {  # as measured with this round's kernels (gpurun_out/r4_tol.log, CRG_TOL_REPORT=1)
+    "bf16": {"c1_latent_rel_l2": 6.4e-2, "c1_pixel_linf": 0.132, "c1_pixel_mean_abs": 1.5e-2},
+    "f16": {"c1_latent_rel_l2": 8.3e-3, "c1_pixel_linf": 1.6e-2, "c1_pixel_mean_abs": 2.0e-3},
+    "fp32": {"c1_latent_rel_l2": 9.3e-5, "c1_pixel_linf": 3.0e-4, "c1_pixel_mean_abs": 3.9e-5},
 }
 
 
 def parity_of(kind):
     d = dict(PARITY[kind])
     d.update({"dtype": {"bf16": "bf16", "f16": "fp16", "fp32": "fp32-class (split-bf16 x3)"}[kind] + " UNet + fp32-class VAE",
-              "vae_pixel_linf": 1.5e-5, "unet_call_rel_l2": {"bf16": 1.5e-2, "f16": 2.0e-3, "fp32": 2.0e-5}[kind],
+              "vae_pixel_linf": 2.0e-5, "unet_call_rel_l2": {"bf16": 1.5e-2, "f16": 2.0e-3, "fp32": 2.0e-5}[kind],
               "reference": "modules/ldm CPU fp32 (fixtures generated by oracle/gen_golden.py from the reference's own modules)",
               "bounded_by": "tests/test_hip_models.py::test_c1_sd15_full_20_step_trajectory, ::test_fp16_operand_build, ::test_vae_sd15_full_decode_pixels, ::test_unet_sd15_full",
-              "note": "north_star's 1e-3 pixel bound is stated for the VAE decode (met: 1.5e-5); over the whole 20-step trajectory only the fp32-class UNet stays inside 1e-3"})
+              "note": "north_star's 1e-3 pixel bound is stated for the VAE decode (met: 2.0e-5); over the whole 20-step trajectory only the fp32-class UNet stays inside 1e-3"})
     return d
 
 
