@@ -10,11 +10,11 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-graph"
+BENCH="python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra --no-graph"
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -o runc -- $BENCH > "$OUT/${TAG}_stats.log" 2>&1
 echo "stats pass done"
-BENCH1="python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-graph"
+BENCH1="python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-extra --no-graph"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/${TAG}_fetch" -o runc -- $BENCH1 > "$OUT/${TAG}_fetch.log" 2>&1
 echo "fetch pass done"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/${TAG}_write" -o runc -- $BENCH1 > "$OUT/${TAG}_write.log" 2>&1

@@ -37,7 +37,7 @@ def slot_of(name):
     if m:
         wnt, conv, ns = m.group(1), m.group(2) == "1", m.group(3)
     else:
-        m = re.search(r"gemm_glds_kernel<(\d), (bool _Accum, bool, E|[\w ]+, (?:true|false)), \d+, \d+, \d+, (\d+), (?:true|false)(?:, (?:true|false))?>", name)
+        m = re.search(r"gemm_glds_kernel<(\d), (bool _Accum, bool, E|[\w ]+, (?:true|false)), \d+, \d+, \d+, (\d+), (?:true|false)(?:, (?:true|false|\d))?>", name)
         if m:
             wnt, ns = m.group(1), m.group(3)
             conv = m.group(2).startswith("bool _Accum") or m.group(2).endswith("true")
