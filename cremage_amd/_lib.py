@@ -14,7 +14,7 @@ HALF_F16 = os.environ.get("CRG_HALF", "bf16").lower() in ("f16", "fp16", "float1
 LIB_PATH = os.path.abspath(os.environ["CRG_LIB"]) if os.environ.get("CRG_LIB") else os.path.join(_HERE, "libcrg_hip_f16.so" if HALF_F16 else "libcrg_hip.so")
 
 BF16, F32, F16 = 0, 1, 2
-PREC_BF16, PREC_BF16X3 = 0, 1
+PREC_BF16, PREC_BF16X3, PREC_F16MX = 0, 1, 2
 EPI_NONE, EPI_SILU, EPI_GEGLU = 0, 1, 2
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 PACK_LINEAR, PACK_CONV, PACK_GEGLU = 0, 1, 2
@@ -77,6 +77,7 @@ class ConvArgs(C.Structure):
         ("gn_stats", c_void_p),
         ("gn_gamma", c_void_p), ("gn_beta", c_void_p), ("gn_y", c_void_p),
         ("gn_groups", c_int), ("gn_silu", c_int), ("gn_eps", C.c_float),
+        ("mx_log2", c_int * 4),
     ]
 
 
@@ -105,6 +106,10 @@ SIGNATURES = {
     "crg_groupnorm_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_int, c_int, c_float, c_int, c_int]),
     "crg_split_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
+    "crg_split_mx": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int]),
+    "crg_groupnorm_mx": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                 c_int, c_int, c_int]),
+    "crg_pack_weight_mx": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int]),
     "crg_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int]),
     "crg_gemm": (c_int, [c_void_p, c_void_p, C.POINTER(GemmArgs)]),
     "crg_conv2d": (c_int, [c_void_p, c_void_p, C.POINTER(ConvArgs)]),

@@ -218,7 +218,40 @@ __global__ __launch_bounds__(256) void pack_ln_kernel(const ST* __restrict__ src
   }
 }
 
+// conv weight [Cout][Cin][3][3] -> MX planes in the conv's chunk-major K order [Cin / 64][tap][64]: w16 fp16 [Cout][K], w8 [Cout][K / 64][128]
+// (64 e4m3 bytes of half(w) * 2^sh, then 64 of (w - half(w)) * 2^sl); thread = eight consecutive k of one row
+template <typename ST>
+__global__ __launch_bounds__(256) void pack_mx_kernel(const ST* __restrict__ src, _Float16* __restrict__ w16, unsigned char* __restrict__ w8,
+                                                      int n_in, long total8, float sh, float sl) {
+  const int kk = 9 * n_in;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
+    const long d = i * 8;
+    const int o = (int)(d / kk), k = (int)(d - (long)o * kk);
+    const int chunk = k / (9 * 64), r = k - chunk * 9 * 64, tap = r / 64, c0 = r - tap * 64;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)src[((long)o * n_in + chunk * 64 + c0 + e) * 9 + tap];
+    crg_store_mx8(f, w16 + d, w8 + 2 * (d - c0) + c0, sh, sl);
+  }
+}
+
 }  // namespace
+
+extern "C" int crg_pack_weight_mx(crg_ctx* ctx, void* stream, const void* src, int src_dtype, int n_out, int n_in, void* dst16, void* dst8,
+                                  int hi_log2, int lo_log2) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, src && dst16 && dst8 && n_out > 0 && n_in > 0 && n_in % 64 == 0, "pack_weight_mx: 3x3 conv weights with Cin %% 64 == 0 (got %d)", n_in);
+  const long total8 = (long)n_out * n_in * 9 / 8;
+  const int grid = (int)((total8 + 255) / 256 < 4096 ? (total8 + 255) / 256 : 4096);
+  hipStream_t st = (hipStream_t)stream;
+  const float sh = ldexpf(1.f, hi_log2), sl = ldexpf(1.f, lo_log2);
+  if (src_dtype == CRG_F32) hipLaunchKernelGGL(pack_mx_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)src, (_Float16*)dst16, (unsigned char*)dst8, n_in, total8, sh, sl);
+  else if (src_dtype == CRG_BF16) hipLaunchKernelGGL(pack_mx_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)src, (_Float16*)dst16, (unsigned char*)dst8, n_in, total8, sh, sl);
+  else if (src_dtype == CRG_F16) hipLaunchKernelGGL(pack_mx_kernel<_Float16>, dim3(grid), dim3(256), 0, st, (const _Float16*)src, (_Float16*)dst16, (unsigned char*)dst8, n_in, total8, sh, sl);
+  else return crg_fail(ctx, -22, "pack_weight_mx: unsupported source dtype %d", src_dtype);
+  CRG_CHECK_LAUNCH(ctx, "pack_weight_mx");
+  return 0;
+}
 
 extern "C" int crg_pack_ln_weight(crg_ctx* ctx, void* stream, const void* src, int src_dtype, const float* gamma, const float* beta,
                                   const float* bias, int kind, int n_out, int n_in, void* dst_w, float* dst_colsum, float* dst_bias) {

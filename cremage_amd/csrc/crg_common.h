@@ -118,6 +118,41 @@ __device__ __forceinline__ float crg_gelu_erf_f(float x) { return x; }
 __device__ __forceinline__ float crg_gelu_erf_f(float x) { return 0.5f * x * (1.0f + crg_erf_f(x * 0.70710678118654752440f)); }
 #endif
 
+// four floats -> four OCP e4m3 bytes (saturating at +-448), lowest byte first
+__device__ __forceinline__ unsigned crg_pack4_e4m3(float a, float b, float c, float d) {
+  int v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  a = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f);
+  b = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);
+  c = __builtin_fminf(__builtin_fmaxf(c, -448.f), 448.f);
+  d = __builtin_fminf(__builtin_fmaxf(d, -448.f), 448.f);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+#endif
+  return (unsigned)v;
+}
+// MX planes of eight consecutive channels of one pixel / weight row (CRG_PREC_F16MX): fp16 values to p16[0..7], e4m3(half * 2^sh) to
+// p8[0..7] and e4m3((f - half) * 2^sl) to p8[64..71] (p8 = the 128-byte record of the 64-channel chunk, already offset to the channel)
+__device__ __forceinline__ void crg_store_mx8(const float (&f)[8], void* p16, unsigned char* p8, float sh, float sl) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  h8 h;
+  float hf[8], lf[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h[e] = (_Float16)f[e];
+    hf[e] = (float)h[e];
+    lf[e] = f[e] - hf[e];
+  }
+  *reinterpret_cast<h8*>(p16) = h;
+  uint2 a, b;
+  a.x = crg_pack4_e4m3(hf[0] * sh, hf[1] * sh, hf[2] * sh, hf[3] * sh);
+  a.y = crg_pack4_e4m3(hf[4] * sh, hf[5] * sh, hf[6] * sh, hf[7] * sh);
+  b.x = crg_pack4_e4m3(lf[0] * sl, lf[1] * sl, lf[2] * sl, lf[3] * sl);
+  b.y = crg_pack4_e4m3(lf[4] * sl, lf[5] * sl, lf[6] * sl, lf[7] * sl);
+  *reinterpret_cast<uint2*>(p8) = a;
+  *reinterpret_cast<uint2*>(p8 + 64) = b;
+}
+
 template <typename T>
 struct crg_vec8;  // 8 consecutive elements of T, loaded/stored as one (bf16) or two (f32) 16-byte accesses
 template <>

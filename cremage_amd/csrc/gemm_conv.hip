@@ -766,10 +766,29 @@ __global__ __launch_bounds__(256 * KG, ((XT != 0 || CRG_LB_A) && KG == 1 && WMT 
 // neighbouring pixels of the same row).
 // MT = 2: 256-row tiles on eight waves (4 x 2), one block per CU: the weight k-tile is staged once per 256 rows (31 KB per
 // k-tile and 256 x BN outputs instead of 2 x 26 KB).
-template <int WNT, typename YT, bool PAIR, int NS = 1, int KG = 1, int MT = 1>
+// MX (round 4, NS = 2 / KG = 2 only): the fp32-class product on ONE fp16 pass plus two cross terms at fp8 precision on the block-scaled MX
+// matrix instruction.  Plane 0 of both operands is fp16 (x16 = half(x), w16 = half(w)); plane 1 holds, per 64-deep k-tile and row, 64 e4m3
+// bytes of the fp16 value ("hi8", scaled by a power of two) followed by 64 e4m3 bytes of the remainder x - x16 ("lo8") - the same 128 bytes
+// per row and k-tile as a second bf16 plane, so the staging code does not change.  acc += w16 x16 (v_mfma_f32_16x16x32_f16, the group's
+// 32-deep k-step) + BOTH cross terms of the k-tile in ONE v_mfma_scale_f32_16x16x128_f8f6f4 per output tile: its 128-deep contraction is
+// the concatenation [w_lo8 | w_hi8] . [x_hi8 | x_lo8] - lane block l >> 4 = 0, 1 reads the lo8 half of the weight row and the hi8 half of the
+// pixel row, block 2, 3 the other halves (32 bytes per lane and fragment) - which needs the two terms' scale products to be equal (they are:
+// lo8 is stored at 2^11 x the hi8 scale on both sides).  The k-groups share the cross work by weight row tiles.  Per 16 x 16 x 64: 2 x 18
+// cycles per k-group + 33.5 in one of them instead of 3 x 2 x 18 (tools/probes/mx_layout.hip); the cross terms only need ~4 bits: emulated
+// pixel L-inf of the full VAE decode 8e-5 against 2e-5 for bf16 x 3, bound 1e-3 (tools/vae_precision_emul.py); measured 1.9e-5.
+// STATUS (round 4): correct (per-op rel-L2 7.5e-6 against 3.2e-6 for bf16 x 3; full VAE decode pixel L-inf 1.9e-5 against 2.0e-5) but 3-13 %
+// SLOWER than bf16 x 3 on the VAE's shapes (decoder 3x3 convs of a batch of four, tools/mx_probe.py: 23.1 ms against 21.5), so the VAE does
+// not use it by default (ops.VAE_MX).  What was measured on the way: a first form that paired two k-tiles per cross
+// instruction (exec-masked half-wave gathers, operands held across the barrier) 23.6 ms; that form without its cross MFMAs 15.5 ms and with
+// neither gathers nor cross MFMAs 15.4 ms - the main fp16 pass alone, a third of today's matrix work, is 28 % faster; the eight scaled
+// instructions per k-tile and wave then cost 7.7 ms where their bare issue time (33.5 cycles each beside 16 x 18 for the main pass) predicts
+// about 3: in this loop the block-scaled instruction is about twice as expensive as in a bare loop.  Next: e2m3 cross operands (19.5
+// cycles per instruction) and 32 x 32 x 64 tiles.
+template <int WNT, typename YT, bool PAIR, int NS = 1, int KG = 1, int MT = 1, bool MX = false>
 __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void conv3_rowhalo_kernel(GemmP p) {
   static_assert(!PAIR || (sizeof(YT) == 2 && NS == 1), "paired columns: bf16 output, single-plane operands");
   static_assert(MT == 1 || (KG == 1 && NS == 1), "256-row tiles: single-plane operands, no in-block split-K");
+  static_assert(!MX || (NS == 2 && KG == 2 && MT == 1), "MX: the split-plane form on two k-groups");
   constexpr int WMT = 4, NW = 4 * KG * MT;
   constexpr int TP = 128 * MT;  // tile pixels
   constexpr int BN = 32 * WNT;
@@ -930,7 +949,7 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
   bf16x4 r1[PAIR ? WMT : 1];
   f32x4 bpre[WNT];
   const bool pre_res = sizeof(YT) == 2 && p.res && p.splits == 1 && (p.ldr & 3) == 0 && (p.N & 3) == 0;
-  const bool pre_bias = p.bias_mode == CRG_BIAS_COL && p.splits == 1 && (p.N & 3) == 0;
+  const bool pre_bias = !MX && p.bias_mode == CRG_BIAS_COL && p.splits == 1 && (p.N & 3) == 0;  // (MX: no registers to spare: the epilogue loads it)
   if (kg == 0) {
     const int nb = n0 + wn * (16 * WNT);
     if (pre_res) {
@@ -981,27 +1000,84 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
 #ifdef CRG_X3_NOSTAGGER
   constexpr bool STAG = false;
 #else
-  constexpr bool STAG = KG == 2 && WNT == 4;  // (the 160-wide split-plane tile has no registers left for a loop-carried fragment set)
+  // (the 160-wide split-plane tile has no registers left for a loop-carried fragment set; neither has the MX form: with its cross operands
+  //  loop-carried as well it spills 92 bytes per lane and measured 16 % slower than its lockstep loop)
+  constexpr bool STAG = KG == 2 && WNT == 4 && !MX;
 #endif
-  bf16x8 sxf[STAG ? WMT : 1], swf[STAG ? WNT : 1], sxl[STAG && NS == 2 ? WMT : 1], swl[STAG && NS == 2 ? WNT : 1];
+  constexpr bool LO = NS == 2 && !MX;  // a second bf16 plane multiplied on the same instruction (bf16 x 3)
+  bf16x8 sxf[STAG ? WMT : 1], swf[STAG ? WNT : 1], sxl[STAG && LO ? WMT : 1], swl[STAG && LO ? WNT : 1];
   if constexpr (STAG) {
 #pragma unroll
-    for (int j = 0; j < WMT; ++j) { sxf[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; if constexpr (NS == 2) sxl[j] = sxf[j]; }
+    for (int j = 0; j < WMT; ++j) { sxf[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; if constexpr (LO) sxl[j] = sxf[j]; }
 #pragma unroll
-    for (int i = 0; i < WNT; ++i) { swf[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; if constexpr (NS == 2) swl[i] = swf[i]; }
+    for (int i = 0; i < WNT; ++i) { swf[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; if constexpr (LO) swl[i] = swf[i]; }
   }
+  // MX: cross-term operand registers (32 e4m3 bytes per lane and fragment): this k-group's weight row tiles [ci0, ci0 + CW) and all pixel tiles
+  typedef int v8i __attribute__((ext_vector_type(8)));
+  typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+  constexpr int CW = MX ? (WNT + 1) / 2 : 1;
+  const int ci0 = kg * CW;
+  v8i wc[CW], xc[MX ? WMT : 1];
+  if constexpr (MX) {  // (the staggered group multiplies once before its first reads)
+#pragma unroll
+    for (int q = 0; q < CW; ++q) wc[q] = v8i{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < WMT; ++j) xc[j] = v8i{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  const int mx_sa = MX ? p.mx_scale[0][0] : 0, mx_sb = MX ? p.mx_scale[0][1] : 0;  // E8M0 scales: W lo8 and X hi8 (= the hi8 x lo8 product)
+  auto mx_reads = [&](const char* ws, const char* xs, int kw) {
+    if constexpr (MX) {
+      const int cwq = ((fq + 2) & 3) * 2, cxq = fq * 2;  // 16-byte chunks of the 128-byte record: W [lo8 | hi8] order, X [hi8 | lo8]
+#pragma unroll
+      for (int q = 0; q < CW; ++q) {
+        const int i = ci0 + q < WNT ? ci0 + q : WNT - 1;
+        const int row = wn * (16 * WNT) + i * 16 + frow;
+        const u32x4 c0 = *reinterpret_cast<const u32x4*>(ws + WS_BYTES + lds_off(row, cwq));
+        const u32x4 c1 = *reinterpret_cast<const u32x4*>(ws + WS_BYTES + lds_off(row, cwq + 1));
+        wc[q] = v8i{(int)c0[0], (int)c0[1], (int)c0[2], (int)c0[3], (int)c1[0], (int)c1[1], (int)c1[2], (int)c1[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) {
+        const u32x4 c0 = *reinterpret_cast<const u32x4*>(xs + xbuf_bytes + lds_off(xb0[j] + kw, cxq));
+        const u32x4 c1 = *reinterpret_cast<const u32x4*>(xs + xbuf_bytes + lds_off(xb0[j] + kw, cxq + 1));
+        xc[j] = v8i{(int)c0[0], (int)c0[1], (int)c0[2], (int)c0[3], (int)c1[0], (int)c1[1], (int)c1[2], (int)c1[3]};
+      }
+      if (kw != 1 && lin) {  // block-uniform: a tap that would wrap around an image row contributes zeros
+#pragma unroll
+        for (int j = 0; j < WMT; ++j)
+          if ((edge >> (kw == 0 ? j : 8 + j)) & 1u) xc[j] = v8i{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+  };
+  auto mx_cross = [&]() {
+    if constexpr (MX) {
+#pragma unroll
+      for (int q = 0; q < CW; ++q) {
+        if (ci0 + q < WNT) {  // wave-uniform (odd WNT: the second group has one row tile fewer)
+#pragma unroll
+          for (int j = 0; j < WMT; ++j) {
+            // (acc[kg * CW + q] with a compile-time index in each arm: no dynamic register indexing)
+            if (kg == 0) acc[q][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wc[q], xc[j], acc[q][j], 0, 0, 0, mx_sa, 0, mx_sb);
+            else acc[(CW + q) < WNT ? CW + q : 0][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wc[q], xc[j], acc[(CW + q) < WNT ? CW + q : 0][j], 0, 0, 0, mx_sa, 0, mx_sb);
+          }
+        }
+      }
+    }
+  };
   auto stag_mma = [&]() {
     if constexpr (STAG) {
 #pragma unroll
       for (int i = 0; i < WNT; ++i)
 #pragma unroll
         for (int j = 0; j < WMT; ++j) {
-          if constexpr (NS == 2) {
+          if constexpr (LO) {
             acc[i][j] = CRG_MFMA_16x16x32(swl[i], sxf[j], acc[i][j]);
             acc[i][j] = CRG_MFMA_16x16x32(swf[i], sxl[j], acc[i][j]);
           }
-          acc[i][j] = CRG_MFMA_16x16x32(swf[i], sxf[j], acc[i][j]);
+          if constexpr (MX) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, swf[i]), __builtin_bit_cast(h16x8, sxf[j]), acc[i][j], 0, 0, 0);
+          else acc[i][j] = CRG_MFMA_16x16x32(swf[i], sxf[j], acc[i][j]);
         }
+      mx_cross();
     }
   };
   int wbuf = 0;
@@ -1028,14 +1104,14 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
           for (int j = 0; j < WMT; ++j) {
             const int off = lds_off(xb0[j] + kw, kg * 4 + fq);
             sxf[j] = *reinterpret_cast<const bf16x8*>(xs + off);
-            if constexpr (NS == 2) sxl[j] = *reinterpret_cast<const bf16x8*>(xs + xbuf_bytes + off);
+            if constexpr (LO) sxl[j] = *reinterpret_cast<const bf16x8*>(xs + xbuf_bytes + off);
           }
           if (kw != 1 && lin) {
 #pragma unroll
             for (int j = 0; j < WMT; ++j) {
               if ((edge >> (kw == 0 ? j : 8 + j)) & 1u) {
                 sxf[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if constexpr (NS == 2) sxl[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if constexpr (LO) sxl[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
               }
             }
           }
@@ -1043,8 +1119,9 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
           for (int i = 0; i < WNT; ++i) {
             const int off = lds_off(wn * (16 * WNT) + i * 16 + frow, kg * 4 + fq);
             swf[i] = *reinterpret_cast<const bf16x8*>(ws + off);
-            if constexpr (NS == 2) swl[i] = *reinterpret_cast<const bf16x8*>(ws + WS_BYTES + off);
+            if constexpr (LO) swl[i] = *reinterpret_cast<const bf16x8*>(ws + WS_BYTES + off);
           }
+          mx_reads(ws, xs, kw);
         };
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (GB) {
@@ -1066,7 +1143,7 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
         for (int j = 0; j < WMT; ++j) {
           const int off = lds_off(xb0[j] + kw, ks * 4 + fq);
           xf[j] = *reinterpret_cast<const bf16x8*>(xs + off);
-          if constexpr (NS == 2) xl[j] = *reinterpret_cast<const bf16x8*>(xs + xbuf_bytes + off);
+          if constexpr (NS == 2 && !MX) xl[j] = *reinterpret_cast<const bf16x8*>(xs + xbuf_bytes + off);
         }
         if (kw != 1 && lin) {  // block-uniform branch: nothing on the hot path of the other geometries
 #pragma unroll
@@ -1081,8 +1158,17 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
         for (int i = 0; i < WNT; ++i) {
           const int off = lds_off(wn * (16 * WNT) + i * 16 + frow, ks * 4 + fq);
           wf[i] = *reinterpret_cast<const bf16x8*>(ws + off);
-          if constexpr (NS == 2) wl[i] = *reinterpret_cast<const bf16x8*>(ws + WS_BYTES + off);
+          if constexpr (NS == 2 && !MX) wl[i] = *reinterpret_cast<const bf16x8*>(ws + WS_BYTES + off);
         }
+        if constexpr (MX) {
+          mx_reads(ws, xs, kw);
+#pragma unroll
+          for (int i = 0; i < WNT; ++i)
+#pragma unroll
+            for (int j = 0; j < WMT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, wf[i]), __builtin_bit_cast(h16x8, xf[j]), acc[i][j], 0, 0, 0);
+          mx_cross();
+        } else {
 #pragma unroll
         for (int i = 0; i < WNT; ++i)
 #pragma unroll
@@ -1093,6 +1179,7 @@ __global__ __launch_bounds__(256 * KG * MT, (KG == 1 && MT == 1) ? 2 : 1) void c
             }
             acc[i][j] = CRG_MFMA_16x16x32(wf[i], xf[j], acc[i][j]);
           }
+        }
       }
       }
       wbuf ^= 1;
@@ -1726,7 +1813,7 @@ int launch_planes(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     const int ngroups = (p.K / BK) / 3;
     if (knob && p.rowhalo && batch == 1 && p.splits <= ngroups) {
       halo = true;
-      kern = conv3_rowhalo_kernel<WNT, float, false, 2, 2>;
+      kern = p.mx ? conv3_rowhalo_kernel<WNT, float, false, 2, 2, 1, true> : conv3_rowhalo_kernel<WNT, float, false, 2, 2>;
       const int XP = (p.halo_lin || p.Wo > 128) ? 17 : ((128 / p.Wo) * (p.Wo + 2) + 7) / 8;
       lds_bytes = (size_t)2 * 2 * BN * 128 + (size_t)2 * 2 * XP * 1024;
       units = ngroups;  // ... or in (chunk, kernel row) groups
@@ -1736,6 +1823,7 @@ int launch_planes(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
     const size_t cap = halo ? (size_t)(2 * 2 * BN * 128 + 2 * 2 * 18 * 1024) : lds;  // eligible widths need <= 18 pieces per row buffer
     if (int rc = crg_set_dyn_lds(ctx, reinterpret_cast<const void*>(kern), cap, "gemm(planes)")) return rc;
   }
+  if (p.mx && !halo) return crg_fail(ctx, -22, "conv2d: the MX form takes 3x3 / stride 1 / pad 1 convs with Cin %% 64 == 0 (the row-halo kernel's domain)");
   {
     p.ks_q = units / p.splits;
     p.ks_r = units % p.splits;
@@ -1767,7 +1855,7 @@ template <bool CONV>
 int dispatch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, int a_dtype, int y_dtype, int prec, Work wk) {
   // GroupNorm statistics: the bf16 path (paired epilogue / split-K reduce), or the fp32-class conv on pre-split planes (its fp32 epilogue)
   const bool gstat_bf16 = prec == CRG_PREC_BF16 && a_dtype == CRG_BF16 && y_dtype == CRG_BF16 && (p.N & 7) == 0;
-  const bool gstat_planes = prec == CRG_PREC_BF16X3 && a_dtype == CRG_BF16 && y_dtype == CRG_F32 && p.a_lo && !p.a_is_weight && (p.N & 3) == 0;
+  const bool gstat_planes = (prec == CRG_PREC_BF16X3 || prec == CRG_PREC_F16MX) && a_dtype == CRG_BF16 && y_dtype == CRG_F32 && p.a_lo && !p.a_is_weight && (p.N & 3) == 0;
   if (p.gstat && !((gstat_bf16 || gstat_planes) && batch == 1 && p.epi == CRG_EPI_NONE))
     return crg_fail(ctx, -22, "gemm/conv: GroupNorm statistics need bf16 in / out (N %% 8 == 0) or pre-split planes in / fp32 out (N %% 4 == 0), batch 1 and a plain epilogue");
   if (prec == CRG_PREC_BF16) {
@@ -1775,6 +1863,11 @@ int dispatch(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, int a_dtype, int
     if (a_dtype == CRG_BF16 && y_dtype == CRG_F32) return launch_wnt<1, bf16, float, CONV>(ctx, st, p, batch, wk);
     if (a_dtype == CRG_F32 && y_dtype == CRG_BF16) return launch_wnt<1, float, bf16, CONV>(ctx, st, p, batch, wk);
     if (a_dtype == CRG_F32 && y_dtype == CRG_F32) return launch_wnt<1, float, float, CONV>(ctx, st, p, batch, wk);
+  } else if (prec == CRG_PREC_F16MX) {
+    if (CONV && p.mx && y_dtype == CRG_F32 && p.a_lo && p.w_lo && p.epi == CRG_EPI_NONE) {
+      if (p.N % 160 == 0) return launch_planes<5, CONV>(ctx, st, p, batch, wk);
+      return launch_planes<4, CONV>(ctx, st, p, batch, wk);
+    }
   } else if (prec == CRG_PREC_BF16X3) {
     if (a_dtype == CRG_BF16 && y_dtype == CRG_F32 && p.a_lo && !p.a_is_weight && p.epi == CRG_EPI_NONE) {
       if (p.N <= 32) return launch_planes<1, CONV>(ctx, st, p, batch, wk);
@@ -1853,7 +1946,7 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
   CRG_REQUIRE(ctx, a->ksize == 3 || a->ksize == 1, "conv2d: ksize %d unsupported", a->ksize);
   CRG_REQUIRE(ctx, a->C1 % 8 == 0 && a->C2 % 8 == 0, "conv2d: channel counts must be multiples of 8 (C1=%d C2=%d); use crg_conv3x3_small", a->C1, a->C2);
   CRG_REQUIRE(ctx, (a->C2 == 0) == (a->x2 == nullptr), "conv2d: x2/C2 mismatch");
-  CRG_REQUIRE(ctx, a->prec == CRG_PREC_BF16 || a->w_lo, "conv2d: BF16X3 needs the lo weight plane");
+  CRG_REQUIRE(ctx, a->prec == CRG_PREC_BF16 || a->w_lo, "conv2d: BF16X3 / F16MX need the second weight plane");
   CRG_REQUIRE(ctx, a->Cout % 4 == 0 || !a->cvec, "conv2d: a per-sample channel vector needs Cout %% 4 == 0 (got %d)", a->Cout);
   CRG_REQUIRE(ctx, ((uintptr_t)a->x & 15) == 0 && ((uintptr_t)a->w & 15) == 0 && ((uintptr_t)a->bias & 15) == 0 && ((uintptr_t)a->cvec & 15) == 0,
               "conv2d: pointers must be 16-byte aligned");
@@ -1861,8 +1954,16 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
   CRG_REQUIRE(ctx, a->Ho > 0 && a->Wo > 0 && (a->Ho - 1) * a->stride - a->pad_t < Hv && (a->Wo - 1) * a->stride - a->pad_l < Wv,
               "conv2d: output %dx%d inconsistent with input %dx%d stride %d", a->Ho, a->Wo, Hv, Wv, a->stride);
   if (a->x_lo) {
-    CRG_REQUIRE(ctx, a->prec == CRG_PREC_BF16X3 && a->x_dtype == CRG_BF16 && a->y_dtype == CRG_F32 && !a->x2 && ((uintptr_t)a->x_lo & 15) == 0,
-                "conv2d: pre-split activations (x_lo) need prec BF16X3, bf16 planes, fp32 output, no second input");
+    CRG_REQUIRE(ctx, (a->prec == CRG_PREC_BF16X3 || a->prec == CRG_PREC_F16MX) && a->x_dtype == CRG_BF16 && a->y_dtype == CRG_F32 && !a->x2 && ((uintptr_t)a->x_lo & 15) == 0,
+                "conv2d: pre-split activations (x_lo) need prec BF16X3 / F16MX, 16-bit planes, fp32 output, no second input");
+  }
+  if (a->prec == CRG_PREC_F16MX) {
+    CRG_REQUIRE(ctx, a->x_lo && a->w_lo && a->ksize == 3 && a->stride == 1 && Ctot % 64 == 0 && !a->upsample2x,
+                "conv2d: F16MX takes 3x3 / stride 1 convs on MX planes (x = fp16 plane, x_lo = e4m3 pair plane, same for w / w_lo), Cin %% 64 == 0");
+    for (int i = 0; i < 4; ++i) CRG_REQUIRE(ctx, a->mx_log2[i] >= -100 && a->mx_log2[i] <= 100, "conv2d: mx_log2[%d] = %d out of range", i, a->mx_log2[i]);
+    CRG_REQUIRE(ctx, a->mx_log2[1] - a->mx_log2[0] == a->mx_log2[3] - a->mx_log2[2],
+                "conv2d: F16MX computes both cross terms in one instruction: the lo8 / hi8 scale ratio must be the same for w (%d) and x (%d)",
+                a->mx_log2[1] - a->mx_log2[0], a->mx_log2[3] - a->mx_log2[2]);
   }
   GemmP p{};
   p.a = a->x; p.a_lo = a->x_lo; p.x2 = a->x2; p.C1 = a->C1; p.C2 = a->C2; p.Ctot = Ctot;
@@ -1874,12 +1975,19 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
   p.cvec = a->cvec; p.cvec_rows = a->Ho * a->Wo; p.cvec_ld = a->cvec_ld ? a->cvec_ld : a->Cout;
   p.H = a->H; p.W = a->W; p.Ho = a->Ho; p.Wo = a->Wo; p.ks = a->ksize; p.stride = a->stride;
   p.pad_t = a->pad_t; p.pad_l = a->pad_l; p.up = a->upsample2x;
+  if (a->prec == CRG_PREC_F16MX) {
+    // mx_log2 = {w hi8, w lo8, x hi8, x lo8}: each plane stores value * 2^s, the instruction's E8M0 scale undoes it (127 - s).
+    // k-group 0 multiplies w lo8 by x hi8, k-group 1 w hi8 by x lo8.
+    p.mx = 1;
+    p.mx_scale[0][0] = 127 - a->mx_log2[1]; p.mx_scale[0][1] = 127 - a->mx_log2[2];
+    p.mx_scale[1][0] = 127 - a->mx_log2[0]; p.mx_scale[1][1] = 127 - a->mx_log2[3];
+  }
   p.gstat = a->gn_stats; p.gstat_plane = (long)((p.M + 31) / 32) * p.N;
   if (a->gn_stats) CRG_REQUIRE(ctx, ((uintptr_t)a->gn_stats & 15) == 0 && (a->Ho * a->Wo) % 32 == 0, "conv2d: gn_stats must be 16-byte aligned and Ho * Wo a multiple of 32");
   p.cm = (a->ksize == 3 && Ctot % 64 == 0) ? 1 : 0;  // must match crg_pack_weight's layout rule
   p.rowhalo = (p.cm && a->stride == 1 && a->pad_t == 1 && a->pad_l == 1 && a->Ho == Hv && a->Wo == Wv &&
                a->C1 % 8 == 0 && a->x_dtype == CRG_BF16 &&
-               ((a->y_dtype == CRG_BF16 && a->prec == CRG_PREC_BF16) || (a->y_dtype == CRG_F32 && a->prec == CRG_PREC_BF16X3 && a->x_lo)))
+               ((a->y_dtype == CRG_BF16 && a->prec == CRG_PREC_BF16) || (a->y_dtype == CRG_F32 && (a->prec == CRG_PREC_BF16X3 || a->prec == CRG_PREC_F16MX) && a->x_lo)))
                   ? 1 : 0;
   p.halo_lin = (a->Wo >= 16 && (a->Wo <= 128 ? 128 % a->Wo == 0 : a->Wo % 128 == 0)) ? 0 : 1;  // geometry of the output grid
   {

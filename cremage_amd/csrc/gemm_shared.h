@@ -49,6 +49,9 @@ struct GemmP {
   // W o gamma, and  y = rstd_m * (acc - mean_m * ln_s[n]) + bias'[n]  with (mean, rstd) folded from the producer's ln_parts partials per
   // row (ln_stat[m][q][2]), ln_s[n] = sum_k (W o gamma)[n][k] over the ROUNDED weight, bias' = W beta + bias (in p.bias)
   const float* ln_stat; int ln_parts; const float* ln_s; float ln_eps;
+  // MX form of the fp32-class conv (crg_conv_args.prec = CRG_PREC_F16MX, conv3_rowhalo_kernel<.., MX>): plane 0 fp16, plane 1 the e4m3 pair
+  // (a_lo / w_lo point at it); mx_scale[k-group][0 = W operand, 1 = X operand] = E8M0 byte of that group's cross-term operands
+  int mx; int mx_scale[2][2];
   // GroupNorm(+SiLU) of the finished output (crg_conv_args.gn_y): when the launch is split along K and a (sample, group) slab fits one
   // block, the kernel that sums the K slices normalises as well (splitk_reduce_gn_kernel) - no reduce launch and no second read of y
   const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_groups, gn_silu, gn_hw; void* gn_y;
@@ -56,6 +59,7 @@ struct GemmP {
 
 constexpr int BM = 128;
 constexpr int BK = 64;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Block -> (m-tile, n-tile, k-slice).  The dispatcher deals workgroups round-robin to the 8 XCDs (block L runs on XCD
 // L % 8) and every XCD has its own 4 MB L2, so whatever two XCDs both touch is fetched twice over the fabric.  The host

@@ -126,7 +126,9 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ part, const float* __restrict__ kbuf,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int silu, T* __restrict__ y,
-                                                       bf16* __restrict__ yh, bf16* __restrict__ yl) {
+                                                       bf16* __restrict__ yh, bf16* __restrict__ yl, unsigned char* __restrict__ y8 = nullptr,
+                                                       float mx_sh = 0.f, float mx_sl = 0.f) {
+  // y8 (fp32 inputs only): MX planes (CRG_PREC_F16MX) instead - yh is then the fp16 plane, y8 the e4m3 pair plane (crg_store_mx8)
   // yh / yl (fp32 inputs only): write the result as two bf16 planes, hi = bf16(f) and lo = bf16(f - hi), instead of y - the
   // operand format of the split-bf16 (fp32-class) LDS-DMA conv, so the split costs no extra pass over the tensor
   __shared__ float meanv[GN_MAX_GROUPS], rstdv[GN_MAX_GROUPS];
@@ -186,7 +188,10 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const T* __restrict__ x, 
   T* yb = y + (long)n * HW * C + c0;
   const long plane0 = (long)n * HW * C + c0;
   auto emit = [&](const float (&f)[8], long roff) {
-    if (yh) {
+    if (y8) {
+      const long e = plane0 + roff;  // element index = pixel * C + c0
+      crg_store_mx8(f, reinterpret_cast<_Float16*>(yh) + e, y8 + 2 * (e - (c0 & 63)) + (c0 & 63), mx_sh, mx_sl);
+    } else if (yh) {
       bf16x8 h8, l8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__
 
 static int groupnorm_impl(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* gamma,
                           const float* beta, void* y, bf16* yh, bf16* yl, int N, int HW, int C, int groups, float eps, int fuse_silu,
-                          int dtype) {
+                          int dtype, unsigned char* y8 = nullptr, float mx_sh = 0.f, float mx_sl = 0.f) {
   if (!ctx) return -22;
   CRG_REQUIRE(ctx, N > 0 && HW > 0 && C > 0, "groupnorm: empty input");
   CRG_REQUIRE(ctx, groups > 0 && groups <= GN_MAX_GROUPS && C % groups == 0, "groupnorm: groups=%d C=%d unsupported", groups, C);
@@ -598,7 +603,7 @@ static int groupnorm_impl(crg_ctx* ctx, void* stream, const void* x, const void*
                          part, kbuf, gamma, beta, eps, fuse_silu, (bf16*)y, (bf16*)nullptr, (bf16*)nullptr);
     else
       hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(threads), 0, st, (const float*)x, (const float*)x2, C1, C, HW, groups, rpc, chunks,
-                         part, kbuf, gamma, beta, eps, fuse_silu, (float*)y, yh, yl);
+                         part, kbuf, gamma, beta, eps, fuse_silu, (float*)y, yh, yl, y8, mx_sh, mx_sl);
   }
   CRG_CHECK_LAUNCH(ctx, "groupnorm");
   return 0;
@@ -679,6 +684,42 @@ extern "C" int crg_groupnorm_pre_split(crg_ctx* ctx, void* stream, const void* x
                        mr, (const float*)nullptr, gamma, beta, eps, fuse_silu, (float*)nullptr, (bf16*)y_hi, (bf16*)y_lo);
   }
   CRG_CHECK_LAUNCH(ctx, "groupnorm_pre_split");
+  return 0;
+}
+
+extern "C" int crg_groupnorm_mx(crg_ctx* ctx, void* stream, const void* x, const float* stats, const float* gamma, const float* beta,
+                                void* y16, void* y8, int N, int HW, int C, int groups, float eps, int fuse_silu, int hi_log2, int lo_log2) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, N > 0 && HW > 0 && C > 0 && x && y16 && y8, "groupnorm_mx: empty input");
+  CRG_REQUIRE(ctx, C % 64 == 0 && (((uintptr_t)y16 | (uintptr_t)y8 | (uintptr_t)x) & 15) == 0, "groupnorm_mx: C=%d must be a multiple of 64 and the pointers 16-byte aligned", C);
+  const float sh = ldexpf(1.f, hi_log2), sl = ldexpf(1.f, lo_log2);
+  if (!stats)  // own statistics: the two-pass form of crg_groupnorm_split
+    return groupnorm_impl(ctx, stream, x, nullptr, C, gamma, beta, y16, (bf16*)y16, (bf16*)y16, N, HW, C, groups, eps, fuse_silu, CRG_F32,
+                          (unsigned char*)y8, sh, sl);
+  CRG_REQUIRE(ctx, groups > 0 && groups <= GN_MAX_GROUPS && C % groups == 0 && (C >> 3) <= 512, "groupnorm_mx: groups=%d C=%d unsupported", groups, C);
+  CRG_REQUIRE(ctx, HW % 32 == 0 && C / groups <= 128 && ((uintptr_t)stats & 15) == 0, "groupnorm_mx: producer statistics need HW %% 32 == 0 and groups of <= 128 channels");
+  const long rbs = (long)N * (HW >> 5);
+  float* mr = (float*)crg_scratch(ctx, (size_t)N * groups * 2 * sizeof(float));
+  if (!mr) return crg_fail(ctx, -12, "groupnorm_mx: out of scratch");
+  hipStream_t st = (hipStream_t)stream;
+  const double elems = (double)N * HW * C;
+  {
+    crg_prof_scope ps(ctx, st, CRG_K_GN_STATS, 2.0 * rbs * C, 8.0 * rbs * C);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, st, stats, (const float*)nullptr, C, C, HW, groups, rbs * C, 0L, eps, mr);
+  }
+  {
+    const int threads = (C >> 3) <= 256 ? 256 : 512;
+    int chunks = HW / 64;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 256) chunks = 256;
+    while ((long)chunks * N < 512 && chunks * 8 <= HW && chunks < 256) chunks *= 2;
+    const int rpc = (HW + chunks - 1) / chunks;
+    chunks = (HW + rpc - 1) / rpc;
+    crg_prof_scope ps(ctx, st, CRG_K_GN_APPLY, 5.0 * elems, elems * 8.0);
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(chunks, N), dim3(threads), 0, st, (const float*)x, (const float*)nullptr, C, C, HW, groups, rpc, -1,
+                       mr, (const float*)nullptr, gamma, beta, eps, fuse_silu, (float*)nullptr, (bf16*)y16, (bf16*)y16, (unsigned char*)y8, sh, sl);
+  }
+  CRG_CHECK_LAUNCH(ctx, "groupnorm_mx");
   return 0;
 }
 

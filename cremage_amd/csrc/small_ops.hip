@@ -433,6 +433,33 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 }
 }  // namespace
 
+namespace {
+// fp32 [pixels][C] -> MX planes (CRG_PREC_F16MX): thread = eight channels of one pixel
+__global__ __launch_bounds__(256) void split_mx_kernel(const float* __restrict__ x, _Float16* __restrict__ x16, unsigned char* __restrict__ x8,
+                                                       long n8, int C, float sh, float sl) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const long e = i * 8;  // element index = pixel * C + c0
+    const int c0 = (int)(e % C);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + e), b = *reinterpret_cast<const f32x4*>(x + e + 4);
+    const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    crg_store_mx8(f, x16 + e, x8 + 2 * (e - (c0 & 63)) + (c0 & 63), sh, sl);
+  }
+}
+}  // namespace
+
+extern "C" int crg_split_mx(crg_ctx* ctx, void* stream, const void* x, void* x16, void* x8, int64_t pixels, int C, int hi_log2, int lo_log2) {
+  if (!ctx) return -22;
+  CRG_REQUIRE(ctx, pixels > 0 && C > 0 && C % 64 == 0, "split_mx: C=%d must be a positive multiple of 64", C);
+  CRG_REQUIRE(ctx, (((uintptr_t)x | (uintptr_t)x16 | (uintptr_t)x8) & 15) == 0, "split_mx: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)pixels * C;
+  crg_prof_scope ps(ctx, st, CRG_K_ELEMENTWISE, 6.0 * n, 8.0 * n);
+  hipLaunchKernelGGL(split_mx_kernel, dim3(grid_for(n / 8)), dim3(256), 0, st, (const float*)x, (_Float16*)x16, (unsigned char*)x8, n / 8, C,
+                     ldexpf(1.f, hi_log2), ldexpf(1.f, lo_log2));
+  CRG_CHECK_LAUNCH(ctx, "split_mx");
+  return 0;
+}
+
 extern "C" int crg_split_bf16(crg_ctx* ctx, void* stream, const void* x, void* hi, void* lo, int64_t n) {
   if (!ctx) return -22;
   CRG_REQUIRE(ctx, n > 0 && n % 8 == 0, "split_bf16: element count %ld must be a positive multiple of 8", (long)n);

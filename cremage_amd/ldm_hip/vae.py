@@ -80,6 +80,14 @@ class ResnetBlock(nn.Module):
                 self.nin_shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
 
     def forward(self, x, temb=None):
+        if ops.mx_conv_ok(x, self.conv1.weight) and self.conv2.in_channels % 64 == 0 and self.conv2.out_channels % 4 == 0:
+            # opt-in (CRG_VAE_MX=1): the same block on MX planes (CRG_PREC_F16MX: one fp16 pass + fp8 cross terms), see ops.VAE_MX
+            a16, a8 = self.norm1(x, silu=True, split="mx")
+            h = self.conv1(a16, x_mx=a8, gn_stats=True)
+            a16, a8 = self.norm2(h, silu=True, split="mx")
+            if self.in_channels != self.out_channels:
+                x = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x)
+            return self.conv2(a16, x_mx=a8, residual=x, gn_stats=True)
         if _planes_ok(x, self.conv1) and _planes_ok(x, self.conv2):
             # fp32-class: GroupNorm+swish writes the two bf16 planes the conv's LDS-DMA kernel stages (no fp32 round trip)
             hi, lo = self.norm1(x, silu=True, split=True)

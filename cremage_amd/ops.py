@@ -287,6 +287,57 @@ def packed_weight(w: torch.Tensor, kind: int, split: bool) -> Tuple[torch.Tensor
     return _pack_cache.put((w,), (kind, split), (hi, lo))
 
 
+# ---------------------------------------------------------------------------------- MX planes (CRG_PREC_F16MX)
+# The fp32-class 3x3 conv in two matrix passes' worth of cycles instead of three: operands as a fp16 plane plus a plane of e4m3 pairs
+# (include/crg_hip.h, crg_split_mx).  Activations behind GroupNorm + SiLU are O(1): fixed power-of-two scales (hi8: x * 2^4, saturating at
+# |x| = 28 - the cross terms lose precision there, nothing else; lo8: (x - half(x)) * 2^15).  Weights: scales from the tensor's maximum at
+# pack time.  Correct and validated (tests/test_hip_ops.py::test_conv_mx) but measured 7-18 % slower than bf16 x 3 in round 4 (gemm_conv.hip,
+# conv3_rowhalo_kernel<.., MX>: status note), so the VAE uses it only under CRG_VAE_MX=1.
+VAE_MX = __import__("os").environ.get("CRG_VAE_MX", "0") != "0"
+MX_X_LOG2 = (4, 15)
+
+
+def packed_weight_mx(w: torch.Tensor):
+    """(w16 fp16 [Cout, 9 Cin], w8 uint8 [Cout, 9 Cin / 64, 128], hi_log2, lo_log2) of a 3x3 conv weight (crg_pack_weight_mx)."""
+    _need_cuda(w)
+    r = _pack_cache.get((w,), ("mx",))
+    if r is not None:
+        return r
+    src = w.detach().contiguous()
+    if src.dtype not in _DT:
+        src = src.float()
+    n_out, n_in = src.shape[0], src.shape[1]
+    amax = float(src.detach().abs().max().item())  # pack time only (outside graph capture: the warm-up calls pack)
+    import math
+    hi = int(math.floor(math.log2(448.0 / max(amax, 1e-30)))) if amax > 0 else 0
+    hi = max(-60, min(60, hi))
+    lo = hi + 11
+    w16 = torch.empty((n_out, 9 * n_in), dtype=torch.float16, device=w.device)
+    w8 = torch.empty((n_out, 9 * n_in // 64, 128), dtype=torch.uint8, device=w.device)
+    h = _h(w)
+    L.check(L.load().crg_pack_weight_mx(h, _st(), _p(src), _dt(src), n_out, n_in, _p(w16), _p(w8), hi, lo), h, "crg_pack_weight_mx")
+    return _pack_cache.put((w,), ("mx",), (w16, w8, hi, lo))
+
+
+def _empty_mx(n, c, hh, ww, device):
+    x16 = torch.empty((n, hh, ww, c), dtype=torch.float16, device=device).permute(0, 3, 1, 2)
+    x8 = torch.empty((n, hh, ww, 2 * c), dtype=torch.uint8, device=device)
+    return x16, x8
+
+
+def split_mx(x: torch.Tensor):
+    """fp32 channels-last image -> MX planes (x16 fp16 image, x8 uint8 [N, H, W, 2 C]) for conv2d(x16, ..., x_mx=x8); C % 64 == 0."""
+    _need_cuda(x)
+    x = to_channels_last(x)
+    n, c, hh, ww = x.shape
+    if x.dtype != torch.float32 or c % 64:
+        raise L.CrgError("split_mx: fp32 image with C % 64 == 0 expected")
+    x16, x8 = _empty_mx(n, c, hh, ww, x.device)
+    h = _h(x)
+    L.check(L.load().crg_split_mx(h, _st(), _p(x), _p(x16), _p(x8), n * hh * ww, c, MX_X_LOG2[0], MX_X_LOG2[1]), h, "crg_split_mx")
+    return x16, x8
+
+
 def packed_geglu_bias(b: torch.Tensor) -> torch.Tensor:
     r = _pack_cache.get((b,), ("geglu_bias",))
     if r is None:
@@ -404,6 +455,14 @@ def group_norm(x: torch.Tensor, weight, bias, groups: int, eps: float, silu: boo
     if weight.numel() != c:
         raise L.CrgError(f"group_norm: {weight.numel()} gains for {c} channels")
     h = _h(x)
+    if split == "mx":  # MX planes for the fp32-class 3x3 conv (CRG_PREC_F16MX)
+        if x.dtype != torch.float32 or x2 is not None or c % 64:
+            raise L.CrgError("group_norm(split='mx'): one fp32 input with C % 64 == 0 expected")
+        y16, y8 = _empty_mx(n, c, hh, ww, x.device)
+        st1 = _gn_stats_of(x, hh * ww)
+        L.check(L.load().crg_groupnorm_mx(h, _st(), _p(x), _p(st1), _p(f32_vec(weight)), _p(f32_vec(bias)), _p(y16), _p(y8), n, hh * ww, c, groups, eps,
+                                          int(silu), MX_X_LOG2[0], MX_X_LOG2[1]), h, "crg_groupnorm_mx")
+        return y16, y8
     if split:
         if x.dtype != torch.float32:
             raise L.CrgError("group_norm(split=True) is the fp32-class path: fp32 input expected")
@@ -680,7 +739,8 @@ def split_bf16(x: torch.Tensor):
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, padding=1,
            upsample2x: bool = False, x2: Optional[torch.Tensor] = None, cvec: Optional[torch.Tensor] = None,
-           residual: Optional[torch.Tensor] = None, x_lo: Optional[torch.Tensor] = None, gn_stats: bool = False, gn=None):
+           residual: Optional[torch.Tensor] = None, x_lo: Optional[torch.Tensor] = None, gn_stats: bool = False, gn=None,
+           x_mx: Optional[torch.Tensor] = None):
     """Implicit-GEMM conv over channels-last images.
     `gn` = (weight, bias, groups, eps, silu): also return silu?(GroupNorm(y)) - the norm that follows the conv inside a ResBlock
     (crg_conv_args.gn_y: on the small images of the two lowest UNet levels the launch that sums the K slices normalises as well);
@@ -689,8 +749,12 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     folded into the gather.  `x2`: second half of a virtual channel concat.  `cvec` fp32 [N, Cout] is
     added per sample (timestep embedding); `residual` is added after.  `x_lo`: x is the bf16 hi plane of a pre-split
     fp32 activation and x_lo its lo plane (group_norm(split=True) / split_bf16): fp32-class conv with fp32 output.
-    `gn_stats`: the output feeds a GroupNorm - emit its statistics side channel where the path supports it (bf16, see above)."""
-    _need_cuda(x, weight, bias, x2, cvec, residual, x_lo)
+    `gn_stats`: the output feeds a GroupNorm - emit its statistics side channel where the path supports it (bf16, see above).
+    `x_mx`: x is the fp16 plane and x_mx the e4m3 pair plane of MX-split fp32 activations (split_mx / group_norm(split='mx')): the
+    fp32-class conv on CRG_PREC_F16MX (3x3, stride 1, pad 1, Cin % 64 == 0; fp32 output)."""
+    _need_cuda(x, weight, bias, x2, cvec, residual, x_lo, x_mx)
+    if x_mx is not None:
+        return _conv2d_mx(x, x_mx, weight, bias, stride, padding, upsample2x, x2, cvec, residual, x_lo, gn_stats, gn)
     x = to_channels_last(x)
     if x_lo is not None:
         x_lo = to_channels_last(x_lo)
@@ -759,6 +823,41 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if stats is not None:
         y._crg_gn = (stats, y._version, ho * wo)
     return y if gn is None else (y, y_norm)
+
+
+def _conv2d_mx(x16, x8, weight, bias, stride, padding, upsample2x, x2, cvec, residual, x_lo, gn_stats, gn):
+    x16 = to_channels_last(x16)
+    n, c, hh, ww = x16.shape
+    cout, cin, ks, _ = weight.shape
+    if x16.dtype != torch.float16 or x8.dtype != torch.uint8 or tuple(x8.shape) != (n, hh, ww, 2 * c) or not x8.is_contiguous():
+        raise L.CrgError("conv2d(x_mx=): x must be the fp16 plane [N, C, H, W] (channels-last) and x_mx the uint8 plane [N, H, W, 2 C]")
+    if ks != 3 or stride != 1 or padding not in (1, (1, 1, 1, 1)) or upsample2x or x2 is not None or x_lo is not None or gn is not None or cvec is not None \
+            or cin != c or c % 64:
+        raise L.CrgError("conv2d(x_mx=): 3x3 / stride 1 / pad 1 convs with Cin % 64 == 0 only (no upsample / concat / fused GroupNorm)")
+    w16, w8, whi, wlo = packed_weight_mx(weight)
+    y = empty_image(n, cout, hh, ww, torch.float32, x16.device)
+    if residual is not None:
+        residual = to_channels_last(residual)
+        if residual.shape != y.shape or residual.dtype != y.dtype:
+            raise L.CrgError("conv2d: residual must match the output in shape and dtype")
+    a = L.ConvArgs(x=x16.data_ptr(), x2=None, C1=c, C2=0, w=w16.data_ptr(), w_lo=w8.data_ptr(), bias=_p(f32_vec(bias)).value, cvec=None, cvec_ld=0,
+                   residual=_p(residual).value, y=y.data_ptr(), N=n, H=hh, W=ww, Cout=cout, Ho=hh, Wo=ww, ksize=3, stride=1, pad_t=1, pad_l=1,
+                   upsample2x=0, x_dtype=L.BF16, y_dtype=L.F32, prec=L.PREC_F16MX, x_lo=x8.data_ptr())
+    a.mx_log2[0], a.mx_log2[1], a.mx_log2[2], a.mx_log2[3] = whi, wlo, MX_X_LOG2[0], MX_X_LOG2[1]
+    stats = _gn_stats_buffer(n * hh * ww, cout, hh * ww, HALF, torch.float32, x16.device) if (gn_stats and VAE_GN_STATS and cout % 4 == 0) else None
+    if stats is not None:
+        a.gn_stats = stats.data_ptr()
+    h = _h(x16)
+    L.check(L.load().crg_conv2d(h, _st(), C.byref(a)), h, "crg_conv2d")
+    if stats is not None:
+        y._crg_gn = (stats, y._version, hh * ww)
+    return y
+
+
+def mx_conv_ok(x: torch.Tensor, conv_weight: torch.Tensor) -> bool:
+    """Would conv2d(x16, w, x_mx=...) take this fp32 activation / 3x3 weight pair (and is the MX form enabled)?"""
+    return (VAE_MX and x.is_cuda and x.dtype == torch.float32 and conv_weight.dim() == 4 and conv_weight.shape[2] == 3 and x.shape[1] % 64 == 0
+            and conv_weight.shape[1] == x.shape[1] and conv_weight.shape[0] > 8 and conv_weight.shape[0] % 4 == 0)
 
 
 def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias=None, residual: Optional[torch.Tensor] = None, gn_stats: bool = False) -> torch.Tensor:

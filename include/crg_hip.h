@@ -40,7 +40,11 @@ enum crg_dtype { CRG_BF16 = 0, CRG_F32 = 1, CRG_F16 = 2 };
  *   CRG_PREC_BF16X3 operands split hi+lo bf16, three MFMA passes (hi*hi + hi*lo + lo*hi),
  *                   fp32 accumulate: ~2^-17 relative operand error ("fp32-class"), used for
  *                   the VAE (pixel L-inf <= 1e-3 target) and the fp32 parity configuration. */
-enum crg_prec { CRG_PREC_BF16 = 0, CRG_PREC_BF16X3 = 1 };
+enum crg_prec { CRG_PREC_BF16 = 0, CRG_PREC_BF16X3 = 1,
+                /* fp32-class 3x3 conv in TWO matrix passes' worth of cycles (round 4): operands as MX planes (crg_split_mx / crg_groupnorm_mx /
+                 * crg_pack_weight_mx) - a fp16 plane and a plane of e4m3 pairs; main product fp16 x fp16, the two cross terms at fp8 precision
+                 * on the block-scaled MX matrix instruction; fp32 accumulate and output.  Emulated pixel L-inf of the VAE decode 8e-5 (bound 1e-3) */
+                CRG_PREC_F16MX = 2 };
 
 enum crg_epilogue {
   CRG_EPI_NONE = 0,
@@ -119,6 +123,16 @@ int crg_groupnorm_pre_split(crg_ctx* ctx, void* stream, const void* x, const flo
 int crg_groupnorm_pre(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* stats1,
                       const float* stats2, const float* gamma, const float* beta, void* y, int N, int HW, int C,
                       int groups, float eps, int fuse_silu, int dtype);
+/* MX planes (CRG_PREC_F16MX, round 4) of an fp32 image [pixels][C], C % 64 == 0: x16 = fp16 [pixels][C]; x8 = [pixels][C / 64][128] bytes - per
+ * 64-channel chunk 64 OCP e4m3 values of half(x) * 2^hi_log2 followed by 64 of (x - half(x)) * 2^lo_log2 (saturating).  crg_split_mx: a
+ * plain tensor; crg_groupnorm_mx: GroupNorm(+SiLU) of x written in that form (`stats` = the producing conv's statistics side channel as in
+ * crg_groupnorm_pre_split, or NULL for a statistics pass over x) - the VAE's Normalize + swish in front of a 3x3 conv (model.py:99-121);
+ * crg_pack_weight_mx: a 3x3 conv weight [Cout][Cin][3][3] (Cin % 64 == 0) in the conv's K order, w16 [Cout][9 Cin], w8 [Cout][9 Cin / 64][128]. */
+int crg_split_mx(crg_ctx* ctx, void* stream, const void* x, void* x16, void* x8, int64_t pixels, int C, int hi_log2, int lo_log2);
+int crg_groupnorm_mx(crg_ctx* ctx, void* stream, const void* x, const float* stats, const float* gamma, const float* beta, void* y16, void* y8,
+                     int N, int HW, int C, int groups, float eps, int fuse_silu, int hi_log2, int lo_log2);
+int crg_pack_weight_mx(crg_ctx* ctx, void* stream, const void* src, int src_dtype, int n_out, int n_in, void* dst16, void* dst8, int hi_log2,
+                       int lo_log2);
 /* fp32 tensor -> the same two bf16 planes (n elements, n % 8 == 0): for fp32-class convs whose input does not come from a
  * GroupNorm (the VAE's Upsample / Downsample convs on the residual stream, model.py:60-64,79-86). */
 int crg_split_bf16(crg_ctx* ctx, void* stream, const void* x, void* hi, void* lo, int64_t n);
@@ -236,6 +250,9 @@ typedef struct {
    * The result is bitwise that of the two separate calls. */
   const float* gn_gamma; const float* gn_beta; void* gn_y;
   int gn_groups; int gn_silu; float gn_eps;
+  /* prec = CRG_PREC_F16MX: x / w are the fp16 planes, x_lo / w_lo the e4m3 pair planes; mx_log2 = {w hi8, w lo8, x hi8, x lo8}: the power of
+   * two each fp8 half was multiplied by when it was written (crg_pack_weight_mx / crg_split_mx / crg_groupnorm_mx take the same numbers) */
+  int mx_log2[4];
 } crg_conv_args;
 int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* args);
 

@@ -311,6 +311,22 @@ def test_vae_sd15_full_decode_pixels():
     assert linf < 1e-3 + 2.5e-4 * max(1.0, float(g["pix_stats"][2]))
 
 
+def test_vae_sd15_full_decode_pixels_mx(monkeypatch):
+    """The same full-size decode with the ResnetBlock convs on MX planes (CRG_PREC_F16MX, opt-in: ops.VAE_MX) - one fp16 pass plus fp8 cross
+    terms per conv instead of three bf16 passes: the pixel bound 1e-3 must hold with margin (CPU emulation of the scheme: 8e-5)."""
+    from cremage_amd import ops
+    from cremage_amd.ldm_hip.vae import AutoencoderKL
+    monkeypatch.setattr(ops, "VAE_MX", True)
+    meta, g = load_golden("vae_sd15_full_decode")
+    m = prep(AutoencoderKL(meta["dd"], None, 4), meta, torch.float32)
+    z = synth_input("vae_full.z", (1, 4, 64, 64), meta["seed"]).to(DEV)
+    with torch.no_grad():
+        dec = m.decode(z / meta["scale_factor"]).cpu()
+    sub = (dec[:, :, ::8, ::8] - g["dec_sub"]).abs().max().item()
+    print(f"\n[parity] SD1.5 VAE decode on MX planes: L-inf on the fp32 subsample {sub / 2:.3e} (pixel units)")
+    assert sub / 2 < 2.5e-4
+
+
 def test_vae_sd15_full_encode():
     from cremage_amd.ldm_hip.vae import AutoencoderKL
     meta, g = load_golden("vae_sd15_full_encode")

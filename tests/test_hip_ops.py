@@ -492,6 +492,69 @@ def test_conv_gn_fused(N, C1, C2, H, W, Co, res):
     check(yn, refn, BF, "conv_gn normalised")
 
 
+def _mx_decode(x8, c, hi_log2, lo_log2):
+    """(hi8, lo8) planes of an MX pair plane [..., 2 C] uint8 as fp32 tensors [..., C] with the scales undone"""
+    v = x8.view(torch.float8_e4m3fn).float().reshape(x8.shape[:-1] + (c // 64, 2, 64))
+    return (v[..., 0, :] * 2.0 ** -hi_log2).reshape(x8.shape[:-1] + (c,)), (v[..., 1, :] * 2.0 ** -lo_log2).reshape(x8.shape[:-1] + (c,))
+
+
+def test_mx_planes_of_split_and_groupnorm():
+    """crg_split_mx / crg_groupnorm_mx: the fp16 plane is half(x); the pair plane holds OCP e4m3 of half(x) * 2^4 and of (x - half(x)) * 2^15
+    (saturating) per 64-channel chunk - decoded here with torch's float8_e4m3fn, so an encoding mismatch (fnuz) would show as a factor 2."""
+    from cremage_amd import ops
+    dev = _dev()
+    x = rnd(2, 128, 16, 32, seed=601) * 3.0
+    x[0, 5, 3, 7] = 100.0  # beyond the hi8 range: saturates at 28, must not wrap
+    xd = nhwc(x, torch.float32)
+    x16, x8 = ops.split_mx(xd)
+    ref16 = x.to(torch.float16)
+    assert torch.equal(x16.cpu().contiguous(), ref16)
+    hi, lo = _mx_decode(x8.cpu(), 128, *ops.MX_X_LOG2)
+    xl = x.permute(0, 2, 3, 1)
+    h16 = ref16.float().permute(0, 2, 3, 1)
+    sat = h16.clamp(-28.0, 28.0)
+    assert ((hi - sat).abs() <= sat.abs() * 2.0 ** -4 + 2.0 ** -13).all()           # 3 mantissa bits, subnormals below 2^-6 / 16
+    assert ((lo - (xl - h16)).abs() <= (xl - h16).abs() * 2.0 ** -4 + 2.0 ** -24).all()
+    assert abs(hi[0, 3, 7, 5].item() - 28.0) < 1e-6
+    g, be = 1.0 + 0.2 * rnd(128, seed=602), 0.1 * rnd(128, seed=603)
+    y16, y8 = ops.group_norm(xd, g.to(dev), be.to(dev), 32, 1e-6, silu=True, split="mx")
+    ref = F.silu(F.group_norm(x, 32, g, be, 1e-6))
+    assert ((y16.float().cpu() - ref).abs() <= ref.abs() * 2.0 ** -10 + 1e-6).all()
+    hi, lo = _mx_decode(y8.cpu(), 128, *ops.MX_X_LOG2)
+    rec = y16.float().cpu().permute(0, 2, 3, 1) + lo                                    # fp16 plane + lo8 remainder ~ the fp32 value
+    assert ((rec - ref.permute(0, 2, 3, 1)).abs() <= ref.permute(0, 2, 3, 1).abs() * 2.0 ** -14 + 1e-6).all()
+
+
+@pytest.mark.parametrize("N,C,H,W,Co,res", [(2, 128, 32, 32, 128, True),     # rows mode (four image rows per tile), one n-tile
+                                            (1, 256, 16, 64, 256, False),    # two image rows per tile
+                                            (1, 128, 8, 256, 128, True),     # row segments
+                                            (2, 64, 6, 24, 64, False),       # linear buffer (width 24), three k-tiles per slice group: odd k-tile counts
+                                            (2, 512, 8, 8, 512, True),       # split-K: slices of an odd number of k-tiles end on a half pair
+                                            (1, 128, 64, 64, 512, False),    # four n-tiles
+                                            (1, 192, 16, 16, 320, False)])   # 160-wide tiles (the spilling instantiation still has to be right)
+def test_conv_mx(N, C, H, W, Co, res):
+    """CRG_PREC_F16MX: the fp32-class 3x3 conv as one fp16 pass + two cross terms on the block-scaled MX matrix instruction, against the fp32
+    torch conv: per-op error ~1e-5 (bf16 x 3: ~1e-5; one fp16 pass alone: 2e-4), every buffer geometry of the row-halo kernel, split-K with
+    odd k-tile counts, GroupNorm statistics out of the epilogue."""
+    from cremage_amd import ops
+    dev = _dev()
+    x = rnd(N, C, H, W, seed=610)
+    w, b = rnd(Co, C, 3, 3, seed=611, scale=(9 * C) ** -0.5), rnd(Co, seed=612)
+    r = rnd(N, Co, H, W, seed=613) if res else None
+    ref = F.conv2d(x, w, b, padding=1) + (r if res else 0)
+    x16, x8 = ops.split_mx(nhwc(x, torch.float32))
+    y = ops.conv2d(x16, w.to(dev), b.to(dev), x_mx=x8, residual=nhwc(r, torch.float32) if res else None, gn_stats=True)
+    assert y.dtype == torch.float32
+    rel = ((y.cpu() - ref).norm() / ref.norm()).item()
+    one_pass = ((F.conv2d(x.half().float(), w.half().float(), b, padding=1) + (r if res else 0) - ref).norm() / ref.norm()).item()
+    assert rel < 4e-5 and rel < 0.3 * one_pass, (rel, one_pass)
+    st = getattr(y, "_crg_gn", None)
+    if H * W % 32 == 0 and H * W >= 512:
+        assert st is not None
+        s0 = st[0][0].double().cpu().reshape(N, -1, Co).sum(1)
+        assert (s0 - y.double().cpu().sum(dim=(2, 3))).abs().max().item() < 1e-3 * y.abs().sum(dim=(2, 3)).max().item()
+
+
 @pytest.mark.parametrize("N,C,H,W,Co", [(2, 64, 8, 8, 64), (1, 128, 16, 32, 160), (1, 64, 3, 64, 64), (1, 64, 2, 128, 64), (2, 64, 5, 12, 96)])
 def test_conv_rowhalo_upsample(N, C, H, W, Co):
     """nearest-2x upsample folded into the row-halo conv's gather (output-grid geometry, sources at (h >> 1, w >> 1)):
