@@ -41,8 +41,8 @@ def test_struct_layouts_match_header():
             if not decl:
                 continue
             parts = [p.strip() for p in decl.split(",")]
-            names.append(re.findall(r"(\w+)$", parts[0])[0])
-            names += [re.findall(r"(\w+)$", p)[0] for p in parts[1:]]
+            names.append(re.findall(r"(\w+)(?:\[\d+\])?$", parts[0])[0])   # (`int mx_log2[4]`: an array field counts once)
+            names += [re.findall(r"(\w+)(?:\[\d+\])?$", p)[0] for p in parts[1:]]
         assert names == [f[0] for f in cls._fields_], (cname, names)
 
 
