@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 W=/tmp/crg_var_$TAG
 rm -rf "$W"; mkdir -p "$W" "$ROOT/tools/ab"
 cd "$ROOT/cremage_amd/csrc"
-for f in crg_api gemm_conv conv_ring conv_pp gemm_ring lngemm norms attention small_ops; do
+for f in crg_api gemm_conv conv_pp gemm_ring lngemm norms attention small_ops; do
   extra=""; [ "$f" = attention ] && extra="-fno-honor-nans"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" $extra "$@" -c $f.hip -o "$W/$f.o" &
 done

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Dev helper for PMC passes: a few launches of one UNet 3x3 conv shape (argv: Cin Cout hw; default 640 640 64) under whatever CRG_RING says."""
+"""Dev helper for PMC passes: a few launches of one UNet 3x3 conv shape (argv: Cin Cout hw; default 640 640 64)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cremage_amd import ops

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Dev probe: the UNet's Linear / 1x1-conv shapes (B = 8), device time inside a captured graph, for whatever CRG_GEMM_CFG / CRG_ROWRES
+"""Dev probe: the UNet's Linear / 1x1-conv shapes (B = 8), device time inside a captured graph, for whatever CRG_GEMM_CFG
 the process was started with.  Columns: plain, +residual, geglu where the model uses them."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,7 +7,7 @@ from cremage_amd import ops
 from tools.gt import graph_us
 dev = "cuda:0"
 torch.manual_seed(0)
-print({k: os.environ.get(k) for k in ("CRG_GEMM_CFG", "CRG_ROWRES", "CRG_SPLIT_BLOCKS")})
+print({k: os.environ.get(k) for k in ("CRG_GEMM_CFG", "CRG_SPLIT_BLOCKS")})
 tot = 0.0
 # (M, N, K, mode, count per UNet call)
 S = [(32768, 320, 320, "res", 15), (32768, 320, 320, "plain", 5), (32768, 320, 1280, "res", 5),

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Dev probe: the UNet's 3x3 convs (all levels), device time inside a captured graph, for whatever CRG_RING the process was started
+"""Dev probe: the UNet's 3x3 convs (all levels), device time inside a captured graph, for whatever build (CRG_LIB) the process was started
 with (2 = ring kernel, 5 = ping-pong kernel); prints the max abs difference against the fp32 torch conv for one shape as a sanity check."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,7 +7,7 @@ from cremage_amd import ops
 from tools.gt import graph_us
 dev = "cuda:0"
 torch.manual_seed(0)
-print({k: os.environ.get(k) for k in ("CRG_RING", "CRG_LIB")})
+print({k: os.environ.get(k) for k in ("CRG_LIB",)})
 tot = 0.0
 SH = [(8, 320, 320, 64, 12), (8, 640, 320, 64, 2), (8, 960, 320, 64, 1), (8, 640, 640, 64, 1),
       (8, 640, 640, 32, 9), (8, 1280, 640, 32, 2), (8, 1920, 640, 32, 1), (8, 960, 640, 32, 1), (8, 320, 640, 32, 1), (8, 1280, 1280, 32, 1),

@@ -1,13 +1,13 @@
 #!/usr/bin/env python
 """Dev probe: the UNet's 3x3 convs at the 8x8 / 16x16 / 32x32 levels (split-K territory), device time inside a captured graph, for
-whatever CRG_ROWHALO / CRG_RING / CRG_SPLIT_BLOCKS / CRG_SPLIT_MAX the process was started with."""
+whatever CRG_ROWHALO / CRG_SPLIT_BLOCKS / CRG_SPLIT_MAX the process was started with."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cremage_amd import ops
 from tools.gt import graph_us
 dev = "cuda:0"
 torch.manual_seed(0)
-print({k: os.environ.get(k) for k in ("CRG_ROWHALO", "CRG_RING", "CRG_SPLIT_BLOCKS", "CRG_SPLIT_MAX")})
+print({k: os.environ.get(k) for k in ("CRG_ROWHALO", "CRG_SPLIT_BLOCKS", "CRG_SPLIT_MAX")})
 tot = 0.0
 for (N, Cin, Cout, hw, cnt) in [(8, 1280, 1280, 8, 11), (8, 2560, 1280, 8, 3), (8, 1280, 1280, 16, 6), (8, 2560, 1280, 16, 2), (8, 1920, 1280, 16, 1),
                                 (8, 640, 1280, 16, 1), (8, 640, 640, 32, 6), (8, 1280, 640, 32, 1), (8, 1920, 640, 32, 1), (8, 960, 640, 32, 1), (8, 320, 640, 32, 1)]:
