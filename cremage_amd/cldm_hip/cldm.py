@@ -164,6 +164,8 @@ class ControlNet(nn.Module):
 
     # shared with the UNet: batched timestep-embedding projections, dtype policy, context cast
     _emb_projections = UNetModel._emb_projections
+    _emb_rows = UNetModel._emb_rows
+    _emb_table = UNetModel._emb_table
     resolve_compute_dtype = UNetModel.resolve_compute_dtype
     _prologue = UNetModel._prologue
 

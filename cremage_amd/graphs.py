@@ -94,7 +94,11 @@ class GraphedModule:
         dyn = {k: v for k, v in kw.items() if k not in consts and torch.is_tensor(v)}
         other = {k: v for k, v in kw.items() if k not in consts and not torch.is_tensor(v)}
         dup = bool(getattr(x, "_crg_cfg_dup", False))  # ops.mark_cfg_dup: a different kernel sequence, hence a different graph
-        key = (self._sig(x), dup, tuple((k, self._sig(v)) for k, v in sorted(dyn.items())),
+        # ops.attach_time_rows: the rows riding on a dynamic argument are a dynamic input of their own (a graph captured without
+        # them computes the embedding itself - another kernel sequence)
+        rows = {k: v._crg_time_rows for k, v in dyn.items() if getattr(v, "_crg_time_rows", None) is not None}
+        key = (self._sig(x), dup, tuple((k, self._sig(v), id(rows[k][0]) if k in rows else None, self._sig(rows[k][1]) if k in rows else None)
+                                        for k, v in sorted(dyn.items())),
                tuple((k, id(v), v._version, self._sig(v)) for k, v in sorted(consts.items())), tuple(sorted(other.items())))
         if self.broken:
             return self.module(x, **kw)
@@ -105,7 +109,7 @@ class GraphedModule:
         fresh = g is None
         if g is None:
             try:
-                g = self._capture(key, x, dyn, consts, other)
+                g = self._capture(key, x, dyn, consts, other, rows)
             except Exception as e:
                 if self.strict:
                     raise L.CrgError(f"hipGraph capture failed ({type(e).__name__}: {e})") from e
@@ -118,12 +122,14 @@ class GraphedModule:
         sx.copy_(x)
         for k, v in dyn.items():
             sdyn[k].copy_(v)
+            if k in rows:
+                sdyn[k]._crg_time_rows[1].copy_(rows[k][1])
         graph.replay()
         if not fresh:
             self.replays += 1
         return sout.clone()
 
-    def _capture(self, key, x, dyn, consts, other):
+    def _capture(self, key, x, dyn, consts, other, rows):
         if len(self._graphs) >= self.max_graphs:
             self._graphs.clear()
         dev = x.device
@@ -133,6 +139,8 @@ class GraphedModule:
         if getattr(x, "_crg_cfg_dup", False):
             sx._crg_cfg_dup = True
         sdyn = {k: v.clone() for k, v in dyn.items()}
+        for k, (owner, r) in rows.items():
+            sdyn[k]._crg_time_rows = (owner, r.clone())
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s), torch.no_grad():

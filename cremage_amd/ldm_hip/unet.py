@@ -270,7 +270,10 @@ class UNetModel(nn.Module):
 
     # -- per-step batched timestep-embedding projections ------------------------------
     def _emb_projections(self, emb: torch.Tensor):
-        """All ResBlocks' `emb_layers` Linear(1280 -> Cout) as one [N, 1280] x [sum Cout, 1280]^T GEMM."""
+        return self._emb_table(self._emb_rows(emb))
+
+    def _emb_rows(self, emb: torch.Tensor):
+        """All ResBlocks' `emb_layers` Linear(1280 -> Cout) as one [N, 1280] x [sum Cout, 1280]^T GEMM -> [N, sum Cout] fp32."""
         blocks = self._resblocks
         if blocks is None:
             blocks = self._resblocks = [m for m in self.modules() if isinstance(m, ResBlock)]
@@ -282,13 +285,33 @@ class UNetModel(nn.Module):
                 hit = _embcat_cache.put(ws + bs, (), (torch.cat([w.detach() for w in ws], 0).contiguous(),
                                                       torch.cat([b.detach().float() for b in bs], 0).contiguous()))
         wcat, bcat = hit
-        out = ops.linear(ops.silu(emb), wcat, bcat, out_dtype=torch.float32)   # [N, sum Cout]
+        return ops.linear(ops.silu(emb), wcat, bcat, out_dtype=torch.float32)
+
+    def _emb_table(self, rows: torch.Tensor):
+        """{id(ResBlock): its [N, Cout] slice} of one [N, sum Cout] fp32 projection tensor (_emb_projections / time_rows)."""
+        blocks = self._resblocks
+        if blocks is None:
+            blocks = self._resblocks = [m for m in self.modules() if isinstance(m, ResBlock)]
         table, off = {}, 0
         for b in blocks:
             n = b.out_channels
-            table[id(b)] = out[:, off:off + n]
+            table[id(b)] = rows[:, off:off + n]
             off += n
+        assert off == rows.shape[1], "time rows: width does not match this UNet's ResBlocks"
         return table
+
+    @torch.no_grad()
+    def time_rows(self, t_table: torch.Tensor) -> torch.Tensor:
+        """Everything of a denoising call that depends on the timestep alone, for a whole schedule at once: `t_table` [S, N] (the
+        timesteps of S sampler steps, already expanded to the UNet batch) -> [S, N, sum Cout] fp32, the 22 ResBlocks' `emb_layers`
+        outputs (openaimodel.py:793-796 + :222-228 per block) from ONE pass of the three GEMMs at S * N rows.  A sampler that knows
+        its schedule hands row s to step s with `ops.attach_time_rows(timesteps, rows[s], unet)`; forward then skips the embedding MLP
+        (5 launches and 55 MB of weights per call at batch 8)."""
+        s, n = t_table.shape
+        cdt = self.resolve_compute_dtype()
+        t_emb = timestep_embedding(t_table.reshape(-1), self.model_channels, dtype=cdt)
+        emb = self.time_embed[2](self.time_embed[0](t_emb, act="silu"))
+        return self._emb_rows(emb).view(s, n, -1)
 
     # -- dtype policy ---------------------------------------------------------------------------
     def resolve_compute_dtype(self) -> torch.dtype:
@@ -303,10 +326,17 @@ class UNetModel(nn.Module):
         """timestep embedding MLP (openaimodel.py:793-796) + the per-step batched ResBlock projections + one cast of the
         context per context tensor -> (compute dtype, emb, context)."""
         cdt = self.resolve_compute_dtype()
-        t_emb = timestep_embedding(timesteps, self.model_channels, dtype=cdt)
-        emb = self.time_embed[0](t_emb, act="silu")
-        emb = self.time_embed[2](emb)
-        emb._crg_emb_out = self._emb_projections(emb)
+        rows = ops.time_rows_of(timesteps, self)
+        if rows is not None:
+            # hoisted by the sampler (time_rows): `emb` itself has no other reader in this network, the rows stand in for it
+            assert rows.dim() == 2 and rows.shape[0] == timesteps.shape[0] and rows.dtype == torch.float32
+            emb = rows
+            emb._crg_emb_out = self._emb_table(rows)
+        else:
+            t_emb = timestep_embedding(timesteps, self.model_channels, dtype=cdt)
+            emb = self.time_embed[0](t_emb, act="silu")
+            emb = self.time_embed[2](emb)
+            emb._crg_emb_out = self._emb_projections(emb)
         if context is not None and context.dtype != cdt:
             # cast once per context tensor (identity + version), so that the cross-attention K/V cache, which is
             # keyed on the tensor it receives, keeps hitting across sampler steps

@@ -405,6 +405,27 @@ def dup_batch(t: torch.Tensor) -> torch.Tensor:
     return torch.cat([t, t], 0)
 
 
+# ---------------------------------------------------------------------------------- hoisted timestep work
+# What a UNet call computes from the timestep alone (sinusoid -> time_embed MLP -> SiLU -> the ResBlocks' emb_layers, openaimodel.py:793-796,
+# :222-228) is known for the whole schedule before the first step.  A sampler of this package computes it once (`UNetModel.time_rows`) and
+# hands each step its rows on the timestep tensor, which the reference's containers pass on untouched (ddpm.py:1034, :1517-1519) like the
+# CFG mark above.  The rows name the network they were computed with: a ControlNet that receives the same timesteps ignores them.
+# CRG_TIME_ROWS=0 (dev knob, A/B) computes the embedding inside every call as before.
+TIME_ROWS = __import__("os").environ.get("CRG_TIME_ROWS", "1") != "0"
+
+
+def attach_time_rows(timesteps: torch.Tensor, rows: torch.Tensor, owner) -> torch.Tensor:
+    """Caller's promise: rows == owner.time_rows(timesteps[None])[0] ([N, sum Cout] fp32 of `owner`, a UNetModel)."""
+    timesteps._crg_time_rows = (owner, rows)
+    return timesteps
+
+
+def time_rows_of(timesteps, owner):
+    """The rows attached for `owner`, or None."""
+    tr = getattr(timesteps, "_crg_time_rows", None)
+    return tr[1] if (TIME_ROWS and tr is not None and tr[0] is owner) else None
+
+
 def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """Contiguous NCHW tensor -> channels-last tensor of `dtype` (one transpose+cast kernel)."""
     _need_cuda(x)

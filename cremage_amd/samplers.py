@@ -184,6 +184,14 @@ class LDMWrapperForKDiffusion(nn.Module):
         _, c_in = cv.get_scalings(sigmas)
         return c_in, cv.sigma_to_t(sigmas)
 
+    def time_rows(self, t_rep):
+        """The wrapped UNet's timestep-only work for the whole table of timesteps `t_rep` [S, N] (`UNetModel.time_rows`) as (unet, rows),
+        or None when the network does not offer it; step i attaches rows[i] to its timesteps (`ops.attach_time_rows`)."""
+        dm = getattr(getattr(self.compviz_model.inner_model, "model", None), "diffusion_model", None)
+        f = getattr(dm, "time_rows", None)
+        from . import ops
+        return (dm, f(t_rep)) if (f is not None and t_rep.is_cuda and ops.TIME_ROWS) else None
+
     def eps_pair_pre(self, x, c_in_i, t_row):
         """eps_pair with the step's scalars taken from eps_tables: `c_in_i` a 0-dim device tensor, `t_row` the step's timestep
         already expanded to the doubled batch.  ONE elementwise launch builds cat([x] * 2) * c_in."""
@@ -243,6 +251,18 @@ def _host_sigmas(sigmas, sigmas_host):
     return sigmas.detach().float().cpu() if sigmas_host is None else sigmas_host
 
 
+def _with_time_rows(model, t_rep):
+    """The per-step rows of the timestep table [S, N] as a list, each carrying the UNet's hoisted timestep work when the wrapper
+    offers it (LDMWrapperForKDiffusion.time_rows)."""
+    rows = [t_rep[i] for i in range(t_rep.shape[0])]
+    tr = model.time_rows(t_rep) if hasattr(model, "time_rows") else None
+    if tr is not None:
+        from . import ops
+        for i, r in enumerate(rows):
+            ops.attach_time_rows(r, tr[1][i], tr[0])
+    return rows
+
+
 @torch.no_grad()
 def sample_euler(model, x, sigmas, extra_args=None, callback=None, disable=None, s_churn=0., s_tmin=0., s_tmax=float('inf'),
                  s_noise=1., sigmas_host=None):
@@ -258,7 +278,7 @@ def sample_euler(model, x, sigmas, extra_args=None, callback=None, disable=None,
         if STEP_TABLES and s_churn == 0. and len(sigmas) > 1:  # sigma_hat == sigma on every step: the wrapper's per-step scalars from one vectorised pass
             c_in_all, t_all = model.eps_tables(sigmas[:-1])
             t_rep = t_all.reshape(-1, 1).expand(-1, 2 * x.shape[0]).contiguous()
-            tables = (c_in_all, t_rep)
+            tables = (c_in_all, _with_time_rows(model, t_rep))
     for i in range(len(sigmas) - 1):
         gamma = min(s_churn / (len(sigmas) - 1), 2 ** 0.5 - 1) if s_tmin <= sh[i].item() <= s_tmax else 0.
         eps = torch.randn_like(x) * s_noise
@@ -293,7 +313,7 @@ def sample_euler_ancestral(model, x, sigmas, extra_args=None, callback=None, dis
         tables = STEP_TABLES and len(sigmas) > 1
         if tables:
             c_in_all, t_all = model.eps_tables(sigmas[:-1])
-            t_rep = t_all.reshape(-1, 1).expand(-1, 2 * x.shape[0]).contiguous()
+            t_rep = _with_time_rows(model, t_all.reshape(-1, 1).expand(-1, 2 * x.shape[0]).contiguous())
     for i in range(len(sigmas) - 1):
         if fused:  # scalings + guidance + Euler update + ancestral noise as one kernel (crg_cfg_euler_step)
             from . import ops

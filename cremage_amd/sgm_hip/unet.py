@@ -138,6 +138,8 @@ class UNetModel(nn.Module):
         self.out = nn.Sequential(normalization(ch), SiLU(), zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
 
     _emb_projections = _SD15UNet._emb_projections
+    _emb_rows = _SD15UNet._emb_rows
+    _emb_table = _SD15UNet._emb_table
     resolve_compute_dtype = _SD15UNet.resolve_compute_dtype
 
     def forward(self, x, timesteps=None, context=None, y=None, **kwargs):

@@ -786,6 +786,42 @@ def test_c4_unit_img2img_768_properties():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, BF])
+def test_time_rows_hoisted_out_of_the_call(dtype):
+    """`UNetModel.time_rows` computes the timestep-only work (sinusoid -> time_embed -> the ResBlocks' emb_layers, openaimodel.py:793-796,
+    :222-228) for a whole schedule at once; a call whose timesteps carry their rows (ops.attach_time_rows, what the Euler samplers of
+    this package do) must give the in-call result within the block tolerance, eagerly and through a hipGraph replay that receives
+    DIFFERENT rows per replay; rows computed by another network (the ControlNet case) must be ignored."""
+    from cremage_amd import ops
+    from cremage_amd.graphs import GraphedModule
+    from cremage_amd.ldm_hip.unet import UNetModel
+    meta, g = load_golden("unet_small_sd")
+    cfg = meta["cfg"]
+    m = prep(UNetModel(**cfg), meta, dtype)
+    x = synth_input("trow.x", (4, 4, 16, 16), 5).to(DEV)
+    ctx = synth_input("trow.ctx", (4, 77, cfg["context_dim"]), 6).to(DEV)
+    t_table = torch.tensor([[801.5] * 4, [333.25] * 4, [12.0] * 4], device=DEV)
+    with torch.no_grad():
+        rows = m.time_rows(t_table)
+        assert rows.shape[:2] == (3, 4) and rows.dtype == torch.float32
+        ref = [m(x.clone(), timesteps=t_table[i].clone(), context=ctx) for i in range(3)]
+        got = [m(x.clone(), timesteps=ops.attach_time_rows(t_table[i].clone(), rows[i], m), context=ctx) for i in range(3)]
+        # the rows replace the computation: garbage timesteps with the right rows give the right answer
+        junk = m(x.clone(), timesteps=ops.attach_time_rows(torch.zeros(4, device=DEV), rows[1], m), context=ctx)
+        other = m(x.clone(), timesteps=ops.attach_time_rows(t_table[1].clone(), torch.zeros_like(rows[1]), object()), context=ctx)
+    tol = TOL_BLOCK[dtype]
+    for i in range(3):
+        close(got[i], ref[i].float().cpu(), tol, f"time rows, step {i}")
+    assert torch.equal(junk, got[1]) and torch.equal(other, ref[1])
+    assert not torch.allclose(got[0].float(), got[1].float())
+    gm = GraphedModule(m, scratch_bytes=64 << 20)
+    with torch.no_grad():
+        yg = [gm(x.clone(), timesteps=ops.attach_time_rows(t_table[i].clone(), rows[i], m), context=ctx) for i in range(3)]
+        yp = gm(x.clone(), timesteps=t_table[2].clone(), context=ctx)  # no rows: its own graph, the in-call embedding
+    assert all(torch.equal(a, b) for a, b in zip(yg, got)) and torch.equal(yp, ref[2])
+    assert gm.captures == 2 and gm.replays == 2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, BF])
 @pytest.mark.parametrize("model", ["unet", "controlled"])
 def test_cfg_shared_prefix_matches_full_batch(dtype, model):
     """A batch-doubled call marked with ops.mark_cfg_dup (what the sampler wrapper does for classifier-free guidance,
