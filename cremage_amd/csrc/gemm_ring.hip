@@ -45,6 +45,9 @@ static __device__ __forceinline__ void rg_store8(void* base, unsigned bytes, int
   const auto rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
   u32x2 r;
   __builtin_memcpy(&r, &v, 8);
+#ifdef CRG_RG_ABL_NOSTORE  // timing ablation only: the store goes out of range (dropped by the range check, still issued and counted)
+  voff = (int)0x80000000;
+#endif
   __builtin_amdgcn_raw_buffer_store_b64(r, rs, voff, 0, 0);
 #endif
 }
@@ -265,14 +268,18 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(RingP p) {
 #pragma unroll
       for (int j = 0; j < WMT; ++j) acc[q][j] = CRG_MFMA_16x16x32(wf1[q], xf1[j], acc[q][j]);
   };
+  // LNE: (rstd, mean * rstd) of the rows this lane's accumulators belong to, for the row block ln_tm - kept across the block's tiles: the
+  // partials come from another XCD's writes, i.e. from the fabric (1 - 2 us in front of an epilogue's first store)
+  float rj[LNE ? WMT : 1], mj[LNE ? WMT : 1];
+  int ln_tm = -1;
   // epilogue of this block's i-th tile (exactly NST store instructions per wave), then the accumulators start over
   auto epilogue = [&](int i) {
     int tile_m, tile_n;
     rg_tile(p, (int)blockIdx.x + i * G, tile_m, tile_n);
     const int m0 = tile_m * TM, n0 = tile_n * BN;
     const int nb = n0 + wn * (16 * WNT);
-    float rj[LNE ? WMT : 1], mj[LNE ? WMT : 1];
-    if constexpr (LNE) {
+    if (LNE && tile_m != ln_tm) {  // (consecutive tiles of a block share their rows in both tile orders: one fetch per block, not per tile)
+      ln_tm = tile_m;
       const int mr = m0 + wm * 64 + lane;
       const f32x2 ab = ln_fold_row(p.ln_stat, mr < p.M ? mr : p.M - 1, p.ln_parts);
       const float a = ab[0], b = ab[1];

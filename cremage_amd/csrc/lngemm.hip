@@ -515,6 +515,248 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
   wait_vmcnt<0>();  // the (zero-fill) DMA batches issued past the last k-tile must land before this block's LDS is handed on
 }
 
+
+// ---- GEGLU, two wave groups in opposite phases (round 4) -------------------------------------------------------------------------------
+// At K = 320 the GEGLU epilogue of an n-tile costs a wave MORE vector-ALU cycles (bias, erf-GELU, product, rounding: ~110 per output,
+// 32 outputs per lane) than the tile's 160 MFMAs cost matrix cycles, and in lngemm_kernel all eight waves do the one and then the other:
+// the matrix pipe idles through every epilogue and the vector ALU through every k-tile (ablations on 32768 x 2560 x 320: 82 us, 72 with
+// GELU = identity, 71 with the stores dropped).  Here the two waves of a SIMD are in OPPOSITE phases: waves 0-3 (one per SIMD) multiply
+// the five k-tiles of an even n-tile while waves 4-7 work through the epilogue of the odd n-tile they finished before, in five pieces,
+// one per step - then the roles swap.  A wave's accumulators are idle while it is in its epilogue phase, so no second set is needed;
+// n-tiles are 128 packed columns wide (64 outputs) so that ONE group covers all 128 resident rows (wave tile 32 x 128, as before).
+//   * one block barrier per step (= per weight k-tile of 16 KB); the weight stream is the same n-tile-major sequence as before, through
+//     an 8-slot ring laid over the resident rows once their fragments are in registers (unit u -> slot (u + 5) & 7; seven units in
+//     flight; every wave issues two 1 KiB pieces per step, so `s_waitcnt vmcnt(12)` at the top of step s proves that unit s has landed
+//     whatever stores lie in between - a store that is older than twelve younger operations has long completed);
+//   * the bias lives in LDS (10 KB at N = 2560): a global load in the loop would make the compiler drain the whole DMA queue;
+//   * stores leave in every step instead of in bursts at the n-tile boundaries.
+template <int KT>
+__global__ __launch_bounds__(512, 2) void lngemm_geglu_pp_kernel(LnGemmP p) {
+  constexpr int WNT = 8, WMT = 2, NW = 8, BMR = 128, BN = 128, NSLOT = 8;
+  constexpr int WS_BYTES = BN * 128;        // 16 KB: one unit = (n-tile, k-tile) of the packed weight
+  constexpr int A_KT = BMR * 128;           // 16 KB: one resident k-tile [128 rows][64 k]
+  constexpr int AP = KT * 16 / NW;
+  static_assert(KT <= 5 && (KT * 16) % NW == 0, "the resident rows must fit slots 0 .. 4");
+  constexpr int OOB = (int)0x80000000;
+  constexpr int BIAS_OFF = NSLOT * WS_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Ares = smem;
+  float* const sbias = reinterpret_cast<float*>(smem + BIAS_OFF);
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = wave >> 2, wm = wave & 3;
+  const int m0 = blockIdx.x * BMR;
+  const int rsub = lane >> 3;
+  const int clog = (lane & 7) ^ rsub;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int tiles_n = p.N / BN;             // even (host)
+  const int U = tiles_n * KT;
+
+  // ---- the 128 rows (all K), the bias, the first three weight units (slots 5 .. 7 lie beyond the rows) ----
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    const int pa = wave + NW * i;
+    const int kt = pa >> 4, rg = pa & 15;
+    const int row = m0 + rg * 8 + rsub;
+    const int vo = row < p.M ? (int)((long)row * p.ldx * 2) + clog * 16 : OOB;
+    ln_dma16(p.x, p.x_bytes, Ares + kt * A_KT + rg * 1024, vo, kt * 128);
+  }
+  int wvo[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) wvo[q] = (int)((long)((wave + NW * q) * 8 + rsub) * p.ldw * 2) + clog * 16;
+  int is_nt = 0, is_kt = 0;                 // the unit the next issue() requests
+  auto issue = [&](int u) {                 // past the last unit: rows beyond w_bytes, zero-filled into slots nobody reads
+    char* ws = smem + ((u + 5) & (NSLOT - 1)) * WS_BYTES;
+    const int soff = (int)((long)is_nt * BN * p.ldw * 2) + is_kt * 128;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) ln_dma16(p.w, p.w_bytes, ws + (wave + NW * q) * 1024, wvo[q], soff);
+    if (++is_kt == KT) {
+      is_kt = 0;
+      ++is_nt;
+    }
+  };
+  issue(0);
+  issue(1);
+  issue(2);
+  f32x4 bq[4];  // the bias, on its way to LDS: all loads out before the first wait (N <= 8192, host)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = (t + 512 * r) * 4;
+    bq[r] = (p.bias && i < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto put_bias = [&]() {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = (t + 512 * r) * 4;
+      if (i < p.N) *reinterpret_cast<f32x4*>(sbias + i) = bq[r];
+    }
+  };
+
+  if (p.gamma) {
+    const int c = lane & 7, r8 = lane >> 3;
+    f32x4 g0[KT], g1[KT], b0[KT], b1[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const int k = kt * 64 + c * 8;
+      g0[kt] = *reinterpret_cast<const f32x4*>(p.gamma + k);
+      g1[kt] = *reinterpret_cast<const f32x4*>(p.gamma + k + 4);
+      b0[kt] = *reinterpret_cast<const f32x4*>(p.beta + k);
+      b1[kt] = *reinterpret_cast<const f32x4*>(p.beta + k + 4);
+    }
+    wait_vmcnt<0>();  // rows (and the three weight units, the bias, gamma / beta) have landed
+    put_bias();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const float inv_k = 1.0f / (float)(KT * 64);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = wave * 16 + it * 8 + r8;
+      bf16x8 v[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) v[kt] = *reinterpret_cast<const bf16x8*>(Ares + kt * A_KT + lds_off(row, c));
+      float s = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)v[kt][e];
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      const float mean = s * inv_k;
+      float qv = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = (float)v[kt][e] - mean;
+          qv += d * d;
+        }
+      qv += __shfl_xor(qv, 1);
+      qv += __shfl_xor(qv, 2);
+      qv += __shfl_xor(qv, 4);
+      const float rstd = rsqrtf(qv * inv_k + p.eps);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float ga = e < 4 ? g0[kt][e] : g1[kt][e - 4], be = e < 4 ? b0[kt][e] : b1[kt][e - 4];
+          o[e] = (bf16)(((float)v[kt][e] - mean) * rstd * ga + be);
+        }
+        *reinterpret_cast<bf16x8*>(Ares + kt * A_KT + lds_off(row, c)) = o;
+      }
+    }
+  } else {
+    wait_vmcnt<0>();
+    put_bias();
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // normalised rows (or the raw ones) visible
+  asm volatile("" ::: "memory");
+  // the wave's activation fragments stay in registers for the whole kernel (KT x 2 k-steps x WMT = 80 VGPRs at K = 320)
+  bf16x8 xa[KT][2][WMT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < WMT; ++j)
+        xa[kt][ks][j] = *reinterpret_cast<const bf16x8*>(Ares + kt * A_KT + (lds_off(wm * 32 + j * 16 + frow, fq) ^ (ks << 6)));
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();        // every wave holds its fragments: the rows' LDS becomes ring slots 0 .. 4
+  asm volatile("" ::: "memory");
+  issue(3);
+  issue(4);
+  issue(5);
+  issue(6);
+
+  f32x4 acc[WNT][WMT];
+#pragma unroll
+  for (int i = 0; i < WNT; ++i)
+#pragma unroll
+    for (int j = 0; j < WMT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wb0 = frow * 128 + ((fq ^ (frow & 7)) << 4);  // rows 16 i + frow share (row & 7): + i * 2048; second k-step: ^ 64
+
+  int s = 0;  // step = unit multiplied in it
+  auto top = [&]() {
+    wait_vmcnt<12>();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue(s + 7);  // into the slot of unit s - 1, which every wave finished reading before this barrier
+  };
+  auto mma_step = [&](int kt) {
+    const char* wbase = smem + ((s + 5) & (NSLOT - 1)) * WS_BYTES;
+    bf16x8 wf0[WNT], wf1[WNT];
+#pragma unroll
+    for (int i = 0; i < WNT; ++i) wf0[i] = *reinterpret_cast<const bf16x8*>(wbase + wb0 + i * 2048);
+#pragma unroll
+    for (int i = 0; i < WNT; ++i) wf1[i] = *reinterpret_cast<const bf16x8*>(wbase + (wb0 ^ 64) + i * 2048);
+#pragma unroll
+    for (int i = 0; i < WNT; ++i)
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) acc[i][j] = CRG_MFMA_16x16x32(wf0[i], xa[kt][0][j], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < WNT; ++i)
+#pragma unroll
+      for (int j = 0; j < WMT; ++j) acc[i][j] = CRG_MFMA_16x16x32(wf1[i], xa[kt][1][j], acc[i][j]);
+  };
+  // one (value, gate) tile pair x one 16-row block of n-tile nt: 4 outputs per lane, one 8-byte store; its accumulators start over
+  auto epi_block = [&](int nt, int u2, int j) {
+    const int pn = nt * BN + u2 * 32 + fq * 4;
+    const int jn = nt * (BN / 2) + u2 * 16 + fq * 4;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + pn), bg = *reinterpret_cast<const f32x4*>(sbias + pn + 16);
+    const int m = m0 + wm * 32 + j * 16 + frow;
+    const f32x4 v = acc[2 * u2][j] + bv, g = acc[2 * u2 + 1][j] + bg;
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[e] * crg_gelu_erf_f(g[e]));
+    ln_store8(p.y, p.y_bytes, m < p.M ? (int)(((long)m * p.ldy + jn) * 2) : OOB, o);
+    acc[2 * u2][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[2 * u2 + 1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // piece c = 0 .. KT - 1 of an n-tile's epilogue: its 8 blocks spread as evenly as the step count allows (KT = 5: 2 2 2 1 1)
+  auto epi_piece = [&](int nt, int c) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+      if ((b * KT) / 8 == c) epi_block(nt, b >> 1, b & 1);
+  };
+  if (grp == 0) {
+    for (int nt = 0; nt < tiles_n; nt += 2) {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt, ++s) {
+        top();
+        mma_step(kt);
+      }
+#pragma unroll
+      for (int c = 0; c < KT; ++c, ++s) {
+        top();
+        epi_piece(nt, c);
+      }
+    }
+  } else {
+    for (int nt = 0; nt < tiles_n; nt += 2) {
+#pragma unroll
+      for (int c = 0; c < KT; ++c, ++s) {
+        top();
+        if (nt > 0) epi_piece(nt - 1, c);
+      }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt, ++s) {
+        top();
+        mma_step(kt);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < KT; ++c) epi_piece(tiles_n - 1, c);
+  }
+  wait_vmcnt<0>();  // the zero-fill batches issued past the last unit must land before this block's LDS is handed on
+}
+
 }  // namespace crg_mm
 
 using namespace crg_mm;
@@ -568,6 +810,18 @@ extern "C" int crg_ln_gemm(crg_ctx* ctx, void* stream, const crg_lngemm_args* a)
   int bn;
   static const int use_alias = getenv("CRG_LN_WIDE") ? atoi(getenv("CRG_LN_WIDE")) : 1;  // dev knob: 0 = 128-column GEGLU tiles
   const bool alias = geglu && use_alias && a->N % 256 == 0;
+  static const int use_pp = getenv("CRG_LN_PP") ? atoi(getenv("CRG_LN_PP")) : 1;  // dev knob: 0 = lockstep GEGLU kernel
+  if (alias && use_pp && a->N <= 8192) {
+    kern = lngemm_geglu_pp_kernel<5>;
+    const size_t lds_pp = (size_t)8 * 128 * 128 + (size_t)a->N * 4;
+    if (int rc = crg_set_dyn_lds(ctx, reinterpret_cast<const void*>(kern), 160 * 1024, "ln_gemm")) return rc;
+    const double flops = 2.0 * a->M * (double)a->N * a->K;
+    const double bytes = (double)a->M * a->K * 2 + (double)a->N * a->K * 2 + (double)a->M * n_out * 2;
+    crg_prof_scope ps(ctx, st, CRG_K_LNGEMM, flops, bytes);
+    hipLaunchKernelGGL(kern, dim3((a->M + 127) / 128), dim3(512), lds_pp, st, p);
+    CRG_CHECK_LAUNCH(ctx, "ln_gemm");
+    return 0;
+  }
   if (alias) { kern = lngemm_kernel<8, 5, true, true>; bn = 256; }
   else if (geglu) { kern = lngemm_kernel<4, 5, true>; bn = 128; }
   else if (wide) { kern = lngemm_kernel<5, 5, false>; bn = 160; }

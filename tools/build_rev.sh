@@ -8,10 +8,11 @@ W=/tmp/crg_rev_$TAG
 rm -rf "$W"; mkdir -p "$W" "$ROOT/tools/ab"
 git -C "$ROOT" archive "$REV" cremage_amd/csrc include | tar -x -C "$W"
 cd "$W/cremage_amd/csrc"
-for f in crg_api gemm_conv norms attention small_ops; do
+for src in *.hip; do
+  f=${src%.hip}
   extra=""; [ "$f" = attention ] && grep -q "fno-honor-nans" "$ROOT/cremage_amd/build.py" && extra="-fno-honor-nans"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra -c $f.hip -o $f.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$W/include" $extra -c $f.hip -o $f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/ab/libcrg_$TAG.so" crg_api.o gemm_conv.o norms.o attention.o small_ops.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/ab/libcrg_$TAG.so" *.o
 echo "built tools/ab/libcrg_$TAG.so from $REV"
