@@ -78,6 +78,7 @@ class ConvArgs(C.Structure):
         ("gn_gamma", c_void_p), ("gn_beta", c_void_p), ("gn_y", c_void_p),
         ("gn_groups", c_int), ("gn_silu", c_int), ("gn_eps", C.c_float),
         ("mx_log2", c_int * 4),
+        ("gn_stats_rows", C.POINTER(c_int)),
     ]
 
 
@@ -104,7 +105,7 @@ SIGNATURES = {
     "crg_groupnorm_pre_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                         c_float, c_int]),
     "crg_groupnorm_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                  c_int, c_int, c_float, c_int, c_int]),
+                                  c_int, c_int, c_float, c_int, c_int, c_int, c_int]),
     "crg_split_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "crg_split_mx": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int]),
     "crg_groupnorm_mx": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
@@ -155,8 +156,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.crg_version() != 102:
-        raise CrgError(f"libcrg_hip.so version {lib.crg_version()} does not match the binding (102)")
+    if lib.crg_version() != 103:
+        raise CrgError(f"libcrg_hip.so version {lib.crg_version()} does not match the binding (103)")
     if lib.crg_half_kind() != (1 if HALF_F16 else 0):
         raise CrgError(f"{LIB_PATH} computes in {'fp16' if lib.crg_half_kind() else 'bf16'} but CRG_HALF asks for {'fp16' if HALF_F16 else 'bf16'}")
     _lib = lib

@@ -451,7 +451,27 @@ __global__ __launch_bounds__(512, 2) void conv3_pp_kernel(GemmP p) {
   }
   PP_STAMP(3);
   if constexpr (PAIR) {
-    gemm_epilogue_pairs<WNT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, 0, r2, r1, pre_res, bpre, pre_bias);
+    // tile statistics (p.gstat_rows == TP): the waves' column sums meet in the (now idle) weight ring, 160 threads fold the four row waves
+    float* const tile_lds = (p.gstat && p.gstat_rows == TP) ? reinterpret_cast<float*>(smem) : nullptr;
+    gemm_epilogue_pairs<WNT, WMT>(p, acc, m0, n0, wm, wn, frow, fq, 0, r2, r1, pre_res, bpre, pre_bias, tile_lds);
+    if (tile_lds) {
+      __syncthreads();
+      if (t < BN) {
+        const int wn_ = t / (16 * WNT), col = t - wn_ * (16 * WNT);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+          const float* L1 = tile_lds + (w4 * 2 + wn_) * (32 * WNT);
+          s1 += L1[col];
+          s2 += L1[16 * WNT + col];
+        }
+        const int n = n0 + t;
+        if (n < p.N) {
+          p.gstat[(long)tile_m * p.N + n] = s1;
+          p.gstat[p.gstat_plane + (long)tile_m * p.N + n] = s2;
+        }
+      }
+    }
   } else {
     gemm_epilogue<WNT, bf16, WMT>(p, acc, m0, n0, wm, wn, frow, fq, 0, sid, rres, pre_res, bpre, pre_bias);
   }

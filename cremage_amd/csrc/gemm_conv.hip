@@ -1661,7 +1661,12 @@ int launch_kernel(crg_ctx* ctx, hipStream_t st, GemmP& p, int batch, Work wk) {
                                      : (WNT == 5 ? CRG_K_GEMM_W5 : WNT == 4 ? CRG_K_GEMM_W4 : CRG_K_GEMM_W1));
   crg_prof_scope ps(ctx, st, slot, wk.flops, wk.bytes);
   if constexpr (GLDS && CONV && STAGES == 2 && WMT == 4 && KG == 1 && sizeof(YT) == 2 && (WNT == 4 || WNT == 5)) {
-    if (halo && p.rowhalo == 2 && p.ring) return launch_conv_pp(ctx, st, p, WNT);
+    if (halo && p.rowhalo == 2 && p.ring) {
+      // one statistics partial per 256-pixel tile and channel instead of eight (crg_groupnorm_pre then needs no finalise launch):
+      // paired epilogue, no K slices, tiles that do not straddle samples
+      if (p.gstat && p.gstat_tile_ok && p.pair && p.splits == 1 && (p.Ho * p.Wo) % 256 == 0) p.gstat_rows = 256;
+      return launch_conv_pp(ctx, st, p, WNT);
+    }
   }
   hipLaunchKernelGGL(kern, grid, dim3(threads), lds_bytes, st, p);
   CRG_CHECK_LAUNCH(ctx, "gemm");
@@ -1906,6 +1911,7 @@ extern "C" int crg_gemm(crg_ctx* ctx, void* stream, const crg_gemm_args* a) {
   p.M = a->M; p.N = a->N; p.K = a->K; p.epi = a->epilogue;
   p.cvec = nullptr; p.cvec_rows = 1; p.cvec_ld = 0; p.a_is_weight = a->a_is_weight;
   p.gstat = a->gn_stats; p.gstat_plane = (long)((a->M + 31) / 32) * a->N;
+  p.gstat_rows = 32;
   if (a->gn_stats) CRG_REQUIRE(ctx, ((uintptr_t)a->gn_stats & 15) == 0, "gemm: gn_stats must be 16-byte aligned");
   if (a->vt) {
     const int bn_ = a->N % 160 == 0 ? 160 : 128;
@@ -1983,6 +1989,8 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
     p.mx_scale[1][0] = 127 - a->mx_log2[0]; p.mx_scale[1][1] = 127 - a->mx_log2[3];
   }
   p.gstat = a->gn_stats; p.gstat_plane = (long)((p.M + 31) / 32) * p.N;
+  p.gstat_rows = 32;
+  p.gstat_tile_ok = a->gn_stats != nullptr && a->gn_stats_rows != nullptr;
   if (a->gn_stats) CRG_REQUIRE(ctx, ((uintptr_t)a->gn_stats & 15) == 0 && (a->Ho * a->Wo) % 32 == 0, "conv2d: gn_stats must be 16-byte aligned and Ho * Wo a multiple of 32");
   p.cm = (a->ksize == 3 && Ctot % 64 == 0) ? 1 : 0;  // must match crg_pack_weight's layout rule
   p.rowhalo = (p.cm && a->stride == 1 && a->pad_t == 1 && a->pad_l == 1 && a->Ho == Hv && a->Wo == Wv &&
@@ -2010,6 +2018,7 @@ extern "C" int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* a) {
   ctx->gn_fused = false;
   const int rc = dispatch<true>(ctx, (hipStream_t)stream, p, 1, a->x_dtype, a->y_dtype, a->prec,
                                 Work{flops, bytes, (double)a->N * a->H * a->W * Ctot * crg_dtype_size(a->x_dtype), (double)p.N * p.K * 2});
+  if (a->gn_stats_rows) *a->gn_stats_rows = p.gstat_rows;
   if (rc || !a->gn_y || ctx->gn_fused) return rc;
   // not split along K (or a shape the fused kernel does not take): the GroupNorm runs as its own launch(es) on the finished y
   return crg_groupnorm(ctx, stream, a->y, nullptr, a->Cout, a->gn_gamma, a->gn_beta, a->gn_y, a->N, a->Ho * a->Wo, a->Cout, a->gn_groups,

@@ -36,6 +36,10 @@ struct GemmP {
   // the FINISHED (bf16-rounded) outputs: gstat[0][rb][n] / gstat[1][rb][n], plane stride gstat_plane floats.  Written by the paired
   // epilogue or, for split-K launches, by the reduce kernel; null = none.
   float* gstat; long gstat_plane;
+  // rows per statistics partial: 32 (default), or the tile height where the kernel folds its waves' sums through LDS and writes ONE partial per
+  // tile and channel (conv3_pp_kernel: 256; set by the launch path when the caller takes tile partials, crg_conv_args.gn_stats_rows)
+  int gstat_rows;
+  int gstat_tile_ok;  // the caller reads gstat_rows back (crg_conv_args.gn_stats_rows != NULL): tile partials allowed
   // transposed column range (crg_gemm_args.vt): output columns n >= vt_n0 (a multiple of the tile width) go to
   // vt[(m / vt_T) * (N - vt_n0) + n - vt_n0][m % vt_T] (row length vt_ld) instead of y: the V^T operand of crg_attention out of the
   // same launch as Q | K (gemm_glds_kernel, paired epilogue; null = none)
@@ -291,10 +295,14 @@ __device__ __forceinline__ int unpair_col(int pos) {  // LDS row position within
 // RS: this instantiation also emits the LayerNorm row statistics of its outputs (p.rstat, see GemmP): per row the sum and the sum of
 // squares of the ROUNDED values this wave stores (16 WNT columns), folded over the four 16-lane groups that share a row - two
 // ds_bpermute per value - and stored by the lanes of group 0: 64 contiguous bytes per plane and 16-row tile.
+// tile_lds (block-uniform; needs p.gstat): TILE statistics - the wave sums over ALL its rows and leaves its per-column sums in LDS
+// (tile_lds[wave slot][2][16 WNT], wave slot = wm * 2 + wn) behind a block barrier (every wave is past its K loop: the LDS is free);
+// the calling kernel folds the row waves and writes one partial per tile and column (p.gstat_rows = tile height).
 template <int WNT, int WMT, int SM = 2, bool RS = false>
 __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)[WNT][WMT], int m0, int n0, int wm, int wn, int frow,
                                                     int fq, int bz, const bf16x8 (&r2)[WNT / 2 > 0 ? WNT / 2 : 1][WMT],
-                                                    const bf16x4 (&r1)[WMT], bool has_res, const f32x4 (&bpre)[WNT], bool has_bias) {
+                                                    const bf16x4 (&r1)[WMT], bool has_res, const f32x4 (&bpre)[WNT], bool has_bias,
+                                                    float* tile_lds = nullptr) {
   bf16* Y = reinterpret_cast<bf16*>(p.y) + (long)bz * p.y_bs;
   const int nb = n0 + wn * (16 * WNT);
   float* RS1 = RS ? p.rstat + ((n0 / (32 * WNT)) * 2 + wn) * 2 : nullptr;
@@ -310,7 +318,7 @@ __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)
       const bool valid = m < p.M;
       if constexpr (!STATS) {
         if (!valid) continue;
-      } else if ((j & 1) == 0) {
+      } else if ((j & 1) == 0 && (tile_lds == nullptr || j == 0)) {
 #pragma unroll
         for (int u = 0; u < NG; ++u)
 #pragma unroll
@@ -405,7 +413,42 @@ __device__ __forceinline__ void gemm_epilogue_pairs(const GemmP& p, f32x4 (&acc)
         if (fq == 0 && valid) *reinterpret_cast<f32x2*>(RS1 + (long)m * p.rstat_parts * 2) = f32x2{q1, q2};
       }
       if constexpr (STATS) {
-        if ((j & 1) == 1) {
+        if (tile_lds != nullptr) {
+          if (j == WMT - 1) {
+            float* L1 = tile_lds + (wm * 2 + wn) * (32 * WNT);
+            float* L2 = L1 + 16 * WNT;
+            __syncthreads();  // every wave of the block is past its K loop: the LDS is free
+#pragma unroll
+            for (int u = 0; u < WNT / 2; ++u) {
+              f32x4 a1, b1, a2, b2;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                a1[e] = row16_sum(s1[u][e]);
+                b1[e] = row16_sum(s1[u][4 + e]);
+                a2[e] = row16_sum(s2[u][e]);
+                b2[e] = row16_sum(s2[u][4 + e]);
+              }
+              if (frow == 0) {
+                *reinterpret_cast<f32x4*>(L1 + 32 * u + 8 * fq) = a1;
+                *reinterpret_cast<f32x4*>(L1 + 32 * u + 8 * fq + 4) = b1;
+                *reinterpret_cast<f32x4*>(L2 + 32 * u + 8 * fq) = a2;
+                *reinterpret_cast<f32x4*>(L2 + 32 * u + 8 * fq + 4) = b2;
+              }
+            }
+            if constexpr (WNT & 1) {
+              f32x4 c1, c2;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                c1[e] = row16_sum(t1[e]);
+                c2[e] = row16_sum(t2[e]);
+              }
+              if (frow == 0) {
+                *reinterpret_cast<f32x4*>(L1 + 16 * (WNT - 1) + 4 * fq) = c1;
+                *reinterpret_cast<f32x4*>(L2 + 16 * (WNT - 1) + 4 * fq) = c2;
+              }
+            }
+          }
+        } else if ((j & 1) == 1) {
           // fold the 16 rows held by the lanes of each DPP row (one lane group = one fq = one 8-channel column group), then lane
           // frow == 0 of every group stores its channels' sums for row block rb
           const int row0 = m0 + wm * (16 * WMT) + (j >> 1) * 32;

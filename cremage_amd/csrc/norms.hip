@@ -7,6 +7,7 @@
 namespace {
 
 constexpr int GN_MAX_GROUPS = 32;
+constexpr int GN_TILE_MAX_C = 1280;  // widest input whose tile partials the normalising launch folds itself (2 x C floats of LDS)
 
 // ---- GroupNorm pass 1: partial (sum, sumsq) of (x - K_g) per (sample, chunk, group) --------------
 // K_g = first element of group g in the sample's first pixel: the classic shifted-data form, so the
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int silu, T* __restrict__ y,
                                                        bf16* __restrict__ yh, bf16* __restrict__ yl, unsigned char* __restrict__ y8 = nullptr,
-                                                       float mx_sh = 0.f, float mx_sl = 0.f) {
+                                                       float mx_sh = 0.f, float mx_sl = 0.f, int rows2 = 0) {
   // y8 (fp32 inputs only): MX planes (CRG_PREC_F16MX) instead - yh is then the fp16 plane, y8 the e4m3 pair plane (crg_store_mx8)
   // yh / yl (fp32 inputs only): write the result as two bf16 planes, hi = bf16(f) and lo = bf16(f - hi), instead of y - the
   // operand format of the split-bf16 (fp32-class) LDS-DMA conv, so the split costs no extra pass over the tensor
@@ -136,7 +137,52 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const T* __restrict__ x, 
   const int t = threadIdx.x;
   const int gs = C / groups;
   const int C2 = C - C1;
-  if (n_chunks < 0) {
+  if (n_chunks < -1) {
+    // TILE partials from the producer(s) (crg_conv_args.gn_stats_rows >= 64: per output tile of -n_chunks (source 2: rows2) rows and per
+    // channel the sum and the sum of squares, planes at the 32-row layout's stride): few enough - HW / rows x C x 2 floats per sample, 41 KB
+    // at 8 x 64 x 64 x 320 on 256-row tiles - that every block folds its sample's itself and the gn_finalize launch disappears.
+    // part = source 1 (channels < C1), kbuf = source 2; fp32 per channel, fp64 across a group's channels and for the moments.
+    // thread = channel (coalesced over the channels of a tile's partial row, four tiles in flight), then thread = group over the LDS sums
+    __shared__ float csum[2][GN_TILE_MAX_C];
+    const int rows1 = -n_chunks;
+    const int T1 = HW / rows1, T2 = rows2 > 0 ? HW / rows2 : 0;
+    const long plane1 = (long)gridDim.y * (HW >> 5) * C1, plane2 = (long)gridDim.y * (HW >> 5) * C2;
+    for (int c = t; c < C; c += blockDim.x) {
+      const bool second = c >= C1;
+      const int Cs = second ? C2 : C1, nt = second ? T2 : T1;
+      const long plane = second ? plane2 : plane1;
+      const float* q = (second ? kbuf + (c - C1) : part + c) + (long)n * nt * Cs;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+      int i = 0;
+      for (; i + 3 < nt; i += 4) {
+        const float* q0 = q + (long)i * Cs;
+        const float x0 = q0[0], x1 = q0[Cs], x2 = q0[2 * (long)Cs], x3 = q0[3 * (long)Cs];
+        const float y0 = q0[plane], y1 = q0[plane + Cs], y2 = q0[plane + 2 * (long)Cs], y3 = q0[plane + 3 * (long)Cs];
+        a0 += x0; a1 += x1; a2 += x2; a3 += x3;
+        b0 += y0; b1 += y1; b2 += y2; b3 += y3;
+      }
+      for (; i < nt; ++i) {
+        a0 += q[(long)i * Cs];
+        b0 += q[(long)i * Cs + plane];
+      }
+      csum[0][c] = (a0 + a1) + (a2 + a3);
+      csum[1][c] = (b0 + b1) + (b2 + b3);
+    }
+    __syncthreads();
+    if (t < groups) {
+      double da = 0.0, db = 0.0;
+      for (int cl = 0; cl < gs; ++cl) {
+        da += (double)csum[0][t * gs + cl];
+        db += (double)csum[1][t * gs + cl];
+      }
+      const double cnt = (double)HW * gs;
+      const double md = da / cnt;
+      double var = db / cnt - md * md;
+      if (var < 0.0) var = 0.0;
+      meanv[t] = (float)md;
+      rstdv[t] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  } else if (n_chunks < 0) {
     // statistics already final (gn_finalize_kernel): part = [N][groups] (mean, rstd)
     if (t < groups) {
       meanv[t] = part[((long)n * groups + t) * 2];
@@ -251,13 +297,12 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const T* __restrict__ x, 
 // virtual concat come from the second producer's planes.  No float atomics, bitwise reproducible.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ st1, const float* __restrict__ st2, int C1, int C,
                                                            int HW, int groups, long plane1, long plane2, float eps,
-                                                           float* __restrict__ mr) {
+                                                           float* __restrict__ mr, int rows1 = 32, int rows2 = 32) {
   // block = (group g, sample n); thread = (row-block lane rl, channel cl of the group): a fixed channel per thread, no division
   // in the loop, four independent row blocks (eight loads) in flight per thread
   __shared__ double red[2][4];
   const int g = blockIdx.x, n = blockIdx.y, t = threadIdx.x;
   const int gs = C / groups, C2 = C - C1;
-  const int nrb = HW >> 5;
   const int nrl = 256 / gs;          // row-block lanes (gs <= 128: at least two)
   const int rl = t / gs, cl = t - rl * gs;
   const int c = g * gs + cl;
@@ -265,6 +310,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   if (rl < nrl) {
     const bool second = c >= C1;
     const int Cs = second ? C2 : C1;
+    const int nrb = HW / (second ? rows2 : rows1);  // partials per sample of this channel's producer (32-row blocks, or its tiles)
     const float* q = (second ? st2 + (c - C1) : st1 + c) + (long)n * nrb * Cs;
     const long plane = second ? plane2 : plane1;
     int rb = rl;
@@ -617,7 +663,7 @@ extern "C" int crg_groupnorm(crg_ctx* ctx, void* stream, const void* x, const vo
 
 extern "C" int crg_groupnorm_pre(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* stats1,
                                  const float* stats2, const float* gamma, const float* beta, void* y, int N, int HW, int C,
-                                 int groups, float eps, int fuse_silu, int dtype) {
+                                 int groups, float eps, int fuse_silu, int dtype, int rows1, int rows2) {
   if (!ctx) return -22;
   CRG_REQUIRE(ctx, N > 0 && HW > 0 && C > 0, "groupnorm_pre: empty input");
   CRG_REQUIRE(ctx, dtype == CRG_BF16, "groupnorm_pre: the statistics side channel is a bf16-path feature (dtype %d)", dtype);
@@ -628,14 +674,24 @@ extern "C" int crg_groupnorm_pre(crg_ctx* ctx, void* stream, const void* x, cons
   if (!x2) C1 = C;
   CRG_REQUIRE(ctx, C1 > 0 && C1 <= C && C1 % 8 == 0 && (C - C1) % 8 == 0, "groupnorm_pre: concat split C1=%d of C=%d unsupported", C1, C);
   CRG_REQUIRE(ctx, stats1 && (x2 == nullptr) == (stats2 == nullptr), "groupnorm_pre: one statistics buffer per input");
+  if (rows1 <= 0) rows1 = 32;
+  if (!x2) rows2 = 0;
+  else if (rows2 <= 0) rows2 = 32;
+  CRG_REQUIRE(ctx, rows1 % 32 == 0 && HW % rows1 == 0 && (!x2 || (rows2 % 32 == 0 && HW % rows2 == 0)),
+              "groupnorm_pre: rows per partial (%d, %d) must be multiples of 32 that divide HW=%d", rows1, rows2, HW);
   const long rbs = (long)N * (HW >> 5);
-  float* mr = (float*)crg_scratch(ctx, (size_t)N * groups * 2 * sizeof(float));
-  if (!mr) return crg_fail(ctx, -12, "groupnorm_pre: out of scratch");
   hipStream_t st = (hipStream_t)stream;
   const double elems = (double)N * HW * C;
-  {
+  // tile partials on every input (crg_conv_args.gn_stats_rows / crg_gemm_args.gn_stats_rows >= 64): each apply block folds its sample's
+  // itself - no finalise launch.  32-row partials (327 KB per sample at 8 x 64 x 64 x 320) keep the finalise kernel.
+  const bool fold_in_apply = rows1 >= 64 && (!x2 || rows2 >= 64) && C <= GN_TILE_MAX_C;
+  float* mr = nullptr;
+  if (!fold_in_apply) {
+    mr = (float*)crg_scratch(ctx, (size_t)N * groups * 2 * sizeof(float));
+    if (!mr) return crg_fail(ctx, -12, "groupnorm_pre: out of scratch");
     crg_prof_scope ps(ctx, st, CRG_K_GN_STATS, 2.0 * rbs * C, 8.0 * rbs * C);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, st, stats1, stats2, C1, C, HW, groups, rbs * C1, rbs * (C - C1), eps, mr);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, st, stats1, stats2, C1, C, HW, groups, rbs * C1, rbs * (C - C1), eps, mr,
+                       rows1, x2 ? rows2 : 32);
   }
   {
     const int threads = (C >> 3) <= 256 ? 256 : 512;
@@ -646,8 +702,12 @@ extern "C" int crg_groupnorm_pre(crg_ctx* ctx, void* stream, const void* x, cons
     const int rpc = (HW + chunks - 1) / chunks;
     chunks = (HW + rpc - 1) / rpc;
     crg_prof_scope ps(ctx, st, CRG_K_GN_APPLY, 5.0 * elems, elems * 4.0);
-    hipLaunchKernelGGL(gn_apply_kernel<bf16>, dim3(chunks, N), dim3(threads), 0, st, (const bf16*)x, (const bf16*)x2, C1, C, HW, groups, rpc, -1,
-                       mr, (const float*)nullptr, gamma, beta, eps, fuse_silu, (bf16*)y, (bf16*)nullptr, (bf16*)nullptr);
+    if (fold_in_apply)
+      hipLaunchKernelGGL(gn_apply_kernel<bf16>, dim3(chunks, N), dim3(threads), 0, st, (const bf16*)x, (const bf16*)x2, C1, C, HW, groups, rpc, -rows1,
+                         stats1, stats2, gamma, beta, eps, fuse_silu, (bf16*)y, (bf16*)nullptr, (bf16*)nullptr, (unsigned char*)nullptr, 0.f, 0.f, rows2);
+    else
+      hipLaunchKernelGGL(gn_apply_kernel<bf16>, dim3(chunks, N), dim3(threads), 0, st, (const bf16*)x, (const bf16*)x2, C1, C, HW, groups, rpc, -1,
+                         mr, (const float*)nullptr, gamma, beta, eps, fuse_silu, (bf16*)y, (bf16*)nullptr, (bf16*)nullptr);
   }
   CRG_CHECK_LAUNCH(ctx, "groupnorm_pre");
   return 0;

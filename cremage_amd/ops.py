@@ -150,6 +150,10 @@ def clear_weight_cache():
 GN_STATS = __import__("os").environ.get("CRG_GN_STATS", "1") != "0"  # dev knob: 0 = every GroupNorm computes its own statistics
 GN_STATS_MIN_HW = 512  # smaller images take the single-launch GroupNorm kernel, which reads the tensor once anyway
 VAE_GN_STATS = __import__("os").environ.get("CRG_VAE_GN_STATS", "1") != "0"  # dev knob: 0 = the fp32-class convs emit no statistics
+# Round 4: a producer may report a coarser granularity than 32 rows (crg_conv_args.gn_stats_rows: one partial per 256-pixel tile and channel
+# from the staggered 3x3 conv); the tuple carries it as a fourth element and crg_groupnorm_pre, given tile partials on every input, folds
+# them inside the normalising launch - the finalise launch disappears.  CRG_GN_TILE=0 (dev knob, A/B): 32-row partials everywhere.
+GN_TILE = __import__("os").environ.get("CRG_GN_TILE", "1") != "0"
 
 
 def _gn_stats_buffer(rows: int, cols: int, hw: Optional[int], in_dtype, out_dtype, device) -> Optional[torch.Tensor]:
@@ -165,6 +169,12 @@ def _gn_stats_of(t: torch.Tensor, hw: int) -> Optional[torch.Tensor]:
     if g is None or g[1] != t._version or g[2] != hw or g[0].shape[2] != t.shape[1]:
         return None
     return g[0]
+
+
+def _gn_rows_of(t: Optional[torch.Tensor]) -> int:
+    """Rows per partial of the statistics riding on t (32 unless the producer said otherwise)."""
+    g = getattr(t, "_crg_gn", None) if t is not None else None
+    return int(g[3]) if (g is not None and len(g) > 3) else 32
 
 
 # ---------------------------------------------------------------------------------- LayerNorm as a GEMM epilogue
@@ -399,7 +409,15 @@ def dup_batch(t: torch.Tensor) -> torch.Tensor:
         out = torch.cat([v, v], 0).permute(0, 3, 1, 2)
         g = getattr(t, "_crg_gn", None)
         if g is not None and g[1] == t._version:
-            out._crg_gn = (torch.cat([g[0], g[0]], 1), out._version, g[2])
+            rows = g[3] if len(g) > 3 else 32
+            if rows == 32:
+                st = torch.cat([g[0], g[0]], 1)
+            else:  # tile partials: the first M / rows partials of each plane, sample-major; the plane stride stays that of the 32-row layout
+                used = g[0].shape[1] * 32 // rows
+                st = torch.empty((2, 2 * g[0].shape[1], g[0].shape[2]), dtype=g[0].dtype, device=g[0].device)
+                st[:, :used] = g[0][:, :used]
+                st[:, used:2 * used] = g[0][:, :used]
+            out._crg_gn = (st, out._version, g[2], rows)
         return out
     t = t.contiguous()
     return torch.cat([t, t], 0)
@@ -503,7 +521,7 @@ def group_norm(x: torch.Tensor, weight, bias, groups: int, eps: float, silu: boo
         st2 = _gn_stats_of(x2, hh * ww) if x2 is not None else None
         if st1 is not None and (x2 is None or st2 is not None):
             L.check(L.load().crg_groupnorm_pre(h, _st(), _p(x), _p(x2), c1, _p(st1), _p(st2), _p(f32_vec(weight)), _p(f32_vec(bias)), _p(y),
-                                               n, hh * ww, c, groups, eps, int(silu), L.BF16), h, "crg_groupnorm_pre")
+                                               n, hh * ww, c, groups, eps, int(silu), L.BF16, _gn_rows_of(x), _gn_rows_of(x2)), h, "crg_groupnorm_pre")
             return y
     L.check(L.load().crg_groupnorm(h, _st(), _p(x), _p(x2), c1, _p(f32_vec(weight)), _p(f32_vec(bias)), _p(y), n, hh * ww, c,
                                    groups, eps, int(silu), _act_dt(x)), h, "crg_groupnorm")
@@ -837,12 +855,15 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     stats = _gn_stats_buffer(n * ho * wo, cout, ho * wo, x.dtype, y.dtype, x.device) if (gn_stats and gn is None and (planes or x.dtype == HALF)) else None
     if stats is not None and planes and (cout % 4 or VAE_GN_STATS is False):
         stats = None
+    rows = C.c_int(32)
     if stats is not None:
         a.gn_stats = stats.data_ptr()
+        if GN_TILE and not planes:
+            a.gn_stats_rows = C.pointer(rows)  # the launch reports the granularity it wrote
     h = _h(x)
     L.check(L.load().crg_conv2d(h, _st(), C.byref(a)), h, "crg_conv2d")
     if stats is not None:
-        y._crg_gn = (stats, y._version, ho * wo)
+        y._crg_gn = (stats, y._version, ho * wo, rows.value)
     return y if gn is None else (y, y_norm)
 
 

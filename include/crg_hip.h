@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CRG_VERSION 102
+#define CRG_VERSION 103
 
 typedef struct crg_ctx crg_ctx;
 
@@ -119,10 +119,12 @@ int crg_groupnorm_pre_split(crg_ctx* ctx, void* stream, const void* x, const flo
  * planes [2][N * HW / 32][C1].  This call folds them per (sample, group) - one tiny launch instead of a read of the whole tensor -
  * and applies the normalisation.  Same result as crg_groupnorm up to the summation order of the statistics (fp32 partials of 32
  * values, fp64 fold).  bf16 only; HW % 32 == 0.  Reference call sites as crg_groupnorm (util.py:214-216, openaimodel.py:205-209,
- * 229-236: the GroupNorm32 + SiLU in front of each ResBlock conv).  stats2 pairs with x2 (virtual concat). */
+ * 229-236: the GroupNorm32 + SiLU in front of each ResBlock conv).  stats2 pairs with x2 (virtual concat).  rows1 / rows2 (0 = 32): rows per
+ * partial of stats1 / stats2 as their producers reported them (crg_conv_args.gn_stats_rows); with tile partials (>= 64 rows) on every
+ * input the fold happens inside the normalising launch (HW / rows x C x 2 floats per sample and block) and the finalise launch is gone. */
 int crg_groupnorm_pre(crg_ctx* ctx, void* stream, const void* x, const void* x2, int C1, const float* stats1,
                       const float* stats2, const float* gamma, const float* beta, void* y, int N, int HW, int C,
-                      int groups, float eps, int fuse_silu, int dtype);
+                      int groups, float eps, int fuse_silu, int dtype, int rows1, int rows2);
 /* MX planes (CRG_PREC_F16MX, round 4) of an fp32 image [pixels][C], C % 64 == 0: x16 = fp16 [pixels][C]; x8 = [pixels][C / 64][128] bytes - per
  * 64-channel chunk 64 OCP e4m3 values of half(x) * 2^hi_log2 followed by 64 of (x - half(x)) * 2^lo_log2 (saturating).  crg_split_mx: a
  * plain tensor; crg_groupnorm_mx: GroupNorm(+SiLU) of x written in that form (`stats` = the producing conv's statistics side channel as in
@@ -253,6 +255,12 @@ typedef struct {
   /* prec = CRG_PREC_F16MX: x / w are the fp16 planes, x_lo / w_lo the e4m3 pair planes; mx_log2 = {w hi8, w lo8, x hi8, x lo8}: the power of
    * two each fp8 half was multiplied by when it was written (crg_pack_weight_mx / crg_split_mx / crg_groupnorm_mx take the same numbers) */
   int mx_log2[4];
+  /* optional OUT (host memory, written before the call returns; NULL: 32-row partials, as ever): the granularity of gn_stats this launch
+   * wrote - rows per partial.  32, or the TILE height (256) where the kernel folds its waves' sums itself (round 4: the 256-pixel-tile 3x3
+   * conv with the paired epilogue, Ho * Wo % 256 == 0, no K slices): plane p, partial r, channel c at gn_stats[p * plane + r * Cout + c] with
+   * the SAME plane stride as the 32-row layout (ceil(M / 32) * Cout floats), only the first M / rows partials of each plane used.  Hand
+   * the value to crg_groupnorm_pre (rows1 / rows2): with tile partials on every input it folds them inside the normalising launch. */
+  int* gn_stats_rows;
 } crg_conv_args;
 int crg_conv2d(crg_ctx* ctx, void* stream, const crg_conv_args* args);
 

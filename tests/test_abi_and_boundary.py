@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for sym in _declared():
         assert hasattr(dll, sym), sym
     assert set(_declared()) == set(_lib.SIGNATURES), set(_declared()) ^ set(_lib.SIGNATURES)
-    assert _lib.load().crg_version() == 102
+    assert _lib.load().crg_version() == 103
 
 
 def test_struct_layouts_match_header():

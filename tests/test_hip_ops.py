@@ -702,10 +702,11 @@ def test_group_norm_production_shapes(N, C1, C2, hw, silu):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
 
 
-def _stats_ref(y, hw):
-    """per 32-row block and channel: sum / sum of squares of a channels-last bf16 image, as the producers' side channel defines it"""
+def _stats_ref(y, hw, rows=32):
+    """per `rows`-row block (32, or the producer's tile height) and channel: sum / sum of squares of a channels-last bf16 image, as the
+    producers' side channel defines it"""
     n, c, hh, ww = y.shape
-    t = y.permute(0, 2, 3, 1).reshape(n * hh * ww // 32, 32, c).float()
+    t = y.permute(0, 2, 3, 1).reshape(n * hh * ww // rows, rows, c).float()
     return torch.stack([t.sum(1), (t * t).sum(1)])
 
 
@@ -738,8 +739,10 @@ def test_gn_stats_side_channel(case):
     check(y, ref, BF, case)
     g = getattr(y, "_crg_gn", None)
     assert g is not None, "the producer did not hand over statistics"
-    st = g[0].cpu()
-    want = _stats_ref(y.float().cpu(), g[2])
+    rows = g[3] if len(g) > 3 else 32
+    want = _stats_ref(y.float().cpu(), g[2], rows)
+    assert g[0].shape[1] * 32 == want.shape[1] * rows  # the buffer has the 32-row layout's size; tile partials fill its first M / rows rows
+    st = g[0][:, :want.shape[1]].cpu()
     assert st.shape == want.shape
     assert (st[0] - want[0]).abs().max().item() < 1e-3 * max(1.0, want[0].abs().max().item())
     assert (st[1] - want[1]).abs().max().item() < 1e-4 * want[1].abs().max().item()
@@ -771,6 +774,62 @@ def test_gn_stats_concat_pair():
     got = ops.group_norm(ya, gam, bet, 32, 1e-5, silu=True, x2=yb)
     ref = F.silu(F.group_norm(torch.cat([ya.float().cpu(), yb.float().cpu()], 1), 32, gam.cpu(), bet.cpu(), 1e-5))
     check(got, ref, BF, "gn(pre) concat")
+
+
+def test_gn_tile_partials():
+    """Round 4: the staggered 256-pixel-tile conv folds its waves' sums itself and reports ONE partial per tile and channel
+    (crg_conv_args.gn_stats_rows = 256); crg_groupnorm_pre then folds them inside the normalising launch.  The partials equal the sums
+    over the stored output; GroupNorm over such a tensor, over a virtual concat of two of them (640 + 320 channels: groups that straddle
+    the producers), over a tile-partial tensor next to a 32-row one (the finalise kernel, per-producer granularity) and over a
+    batch-doubled copy (ops.dup_batch) equals the reference."""
+    from cremage_amd import ops
+    dev = _dev()
+    if not ops.GN_TILE:
+        pytest.skip("CRG_GN_TILE=0")
+    N, hw = 8, 64  # the UNet's own 64x64-level shapes (one 256-pixel tile per CU and more)
+
+    def conv(cin, cout, seed):
+        x = rnd(N, cin, hw, hw, seed=seed)
+        w, b = rnd(cout, cin, 3, 3, seed=seed + 1, scale=(9 * cin) ** -0.5), rnd(cout, seed=seed + 2)
+        r = rnd(N, cout, hw, hw, seed=seed + 3)
+        return ops.conv2d(nhwc(x, BF), w.to(dev), b.to(dev), padding=1, residual=nhwc(r, BF), gn_stats=True)
+
+    ya, yb = conv(320, 640, 300), conv(320, 320, 310)
+    for y in (ya, yb):
+        g = y._crg_gn
+        assert len(g) > 3 and g[3] == 256, "the 64x64-level 3x3 conv is expected on the 256-pixel-tile kernel with tile statistics"
+        want = _stats_ref(y.float().cpu(), g[2], 256)
+        st = g[0][:, :want.shape[1]].cpu()
+        assert (st[0] - want[0]).abs().max().item() < 1e-3 * max(1.0, want[0].abs().max().item())
+        assert (st[1] - want[1]).abs().max().item() < 1e-4 * want[1].abs().max().item()
+
+    def gn_ref(*ys):
+        cat = torch.cat([v.float().cpu() for v in ys], 1)
+        c = cat.shape[1]
+        gam, bet = 1 + 0.1 * rnd(c, seed=320 + c), 0.1 * rnd(c, seed=321 + c)
+        return gam.to(dev), bet.to(dev), F.silu(F.group_norm(cat, 32, gam, bet, 1e-5))
+
+    gam, bet, ref = gn_ref(ya)
+    one = ops.group_norm(ya, gam, bet, 32, 1e-5, silu=True)
+    check(one, ref, BF, "gn tile partials")
+    assert torch.equal(one, ops.group_norm(ya, gam, bet, 32, 1e-5, silu=True))
+    gam, bet, ref = gn_ref(ya, yb)  # 960 channels, group size 30: groups straddle the two producers
+    check(ops.group_norm(ya, gam, bet, 32, 1e-5, silu=True, x2=yb), ref, BF, "gn tile partials, concat")
+    # a GEMM-produced image (32-row partials) next to a tile-partial one: per-producer granularity in the finalise kernel
+    t = ops.linear(rnd(N * hw * hw, 64, seed=330).to(dev).to(BF).view(N, hw * hw, 64), rnd(320, 64, seed=331, scale=0.125).to(dev), None, gn_hw=hw * hw)
+    yc = ops.image_of_stats(t, hw, hw)
+    assert ops._gn_rows_of(yc) == 32 and ops._gn_stats_of(yc, hw * hw) is not None
+    gam, bet, ref = gn_ref(yb, yc)
+    check(ops.group_norm(yb, gam, bet, 32, 1e-5, silu=True, x2=yc), ref, BF, "gn tile + 32-row partials")
+    gam, bet, ref = gn_ref(yc, ya)
+    check(ops.group_norm(yc, gam, bet, 32, 1e-5, silu=True, x2=ya), ref, BF, "gn 32-row + tile partials")
+    # the CFG prefix duplicates a tensor together with its statistics
+    yd = ops.dup_batch(yb)
+    assert ops._gn_rows_of(yd) == 256 and ops._gn_stats_of(yd, hw * hw) is not None
+    gam, bet, ref = gn_ref(yb)
+    got = ops.group_norm(yd, gam, bet, 32, 1e-5, silu=True)
+    check(got[:N], ref, BF, "gn tile partials, dup (first half)")
+    assert torch.equal(got[:N], got[N:])
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
