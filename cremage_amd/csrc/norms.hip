@@ -684,7 +684,10 @@ extern "C" int crg_groupnorm_pre(crg_ctx* ctx, void* stream, const void* x, cons
   const double elems = (double)N * HW * C;
   // tile partials on every input (crg_conv_args.gn_stats_rows / crg_gemm_args.gn_stats_rows >= 64): each apply block folds its sample's
   // itself - no finalise launch.  32-row partials (327 KB per sample at 8 x 64 x 64 x 320) keep the finalise kernel.
-  const bool fold_in_apply = rows1 >= 64 && (!x2 || rows2 >= 64) && C <= GN_TILE_MAX_C;
+  // ... while a sample's partials stay small next to the block's own share of the tensor (80 KB: 16 tiles x 640 channels; a 128 x 128 level
+  // has 64 tiles per sample - 490 KB in front of every block of a 960-channel concat - and keeps the finalise launch)
+  const long fold_floats = (long)(HW / rows1) * C1 + (x2 ? (long)(HW / rows2) * (C - C1) : 0);
+  const bool fold_in_apply = rows1 >= 64 && (!x2 || rows2 >= 64) && C <= GN_TILE_MAX_C && fold_floats <= 10240;
   float* mr = nullptr;
   if (!fold_in_apply) {
     mr = (float*)crg_scratch(ctx, (size_t)N * groups * 2 * sizeof(float));
