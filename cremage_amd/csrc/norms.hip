@@ -142,39 +142,39 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const T* __restrict__ x, 
     // channel the sum and the sum of squares, planes at the 32-row layout's stride): few enough - HW / rows x C x 2 floats per sample, 41 KB
     // at 8 x 64 x 64 x 320 on 256-row tiles - that every block folds its sample's itself and the gn_finalize launch disappears.
     // part = source 1 (channels < C1), kbuf = source 2; fp32 per channel, fp64 across a group's channels and for the moments.
-    // thread = channel (coalesced over the channels of a tile's partial row, four tiles in flight), then thread = group over the LDS sums
-    __shared__ float csum[2][GN_TILE_MAX_C];
+    // thread = (four channels, tile subset): 16-byte loads, coalesced along a tile's partial row, every load of the block in flight at once
+    // (a first form with one channel per thread and a second round for C > 256 put two load latencies in front of the block: +3.4 us per
+    // launch against the 5.4 us finalise launch it replaces); then thread = group over the LDS sums
+    __shared__ __attribute__((aligned(16))) float csum[2][2048];
     const int rows1 = -n_chunks;
     const int T1 = HW / rows1, T2 = rows2 > 0 ? HW / rows2 : 0;
     const long plane1 = (long)gridDim.y * (HW >> 5) * C1, plane2 = (long)gridDim.y * (HW >> 5) * C2;
-    for (int c = t; c < C; c += blockDim.x) {
+    const int nq = C >> 2;
+    int TS = blockDim.x / nq;
+    if (TS < 1) TS = 1;
+    for (int w = t; w < nq * TS; w += blockDim.x) {
+      const int ts = w / nq, c = (w - ts * nq) * 4;
       const bool second = c >= C1;
       const int Cs = second ? C2 : C1, nt = second ? T2 : T1;
       const long plane = second ? plane2 : plane1;
       const float* q = (second ? kbuf + (c - C1) : part + c) + (long)n * nt * Cs;
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-      int i = 0;
-      for (; i + 3 < nt; i += 4) {
-        const float* q0 = q + (long)i * Cs;
-        const float x0 = q0[0], x1 = q0[Cs], x2 = q0[2 * (long)Cs], x3 = q0[3 * (long)Cs];
-        const float y0 = q0[plane], y1 = q0[plane + Cs], y2 = q0[plane + 2 * (long)Cs], y3 = q0[plane + 3 * (long)Cs];
-        a0 += x0; a1 += x1; a2 += x2; a3 += x3;
-        b0 += y0; b1 += y1; b2 += y2; b3 += y3;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+#pragma unroll 4
+      for (int i = ts; i < nt; i += TS) {
+        a += *reinterpret_cast<const f32x4*>(q + (long)i * Cs);
+        b += *reinterpret_cast<const f32x4*>(q + (long)i * Cs + plane);
       }
-      for (; i < nt; ++i) {
-        a0 += q[(long)i * Cs];
-        b0 += q[(long)i * Cs + plane];
-      }
-      csum[0][c] = (a0 + a1) + (a2 + a3);
-      csum[1][c] = (b0 + b1) + (b2 + b3);
+      *reinterpret_cast<f32x4*>(&csum[0][ts * C + c]) = a;
+      *reinterpret_cast<f32x4*>(&csum[1][ts * C + c]) = b;
     }
     __syncthreads();
     if (t < groups) {
       double da = 0.0, db = 0.0;
-      for (int cl = 0; cl < gs; ++cl) {
-        da += (double)csum[0][t * gs + cl];
-        db += (double)csum[1][t * gs + cl];
-      }
+      for (int ts = 0; ts < TS; ++ts)
+        for (int cl = 0; cl < gs; ++cl) {
+          da += (double)csum[0][ts * C + t * gs + cl];
+          db += (double)csum[1][ts * C + t * gs + cl];
+        }
       const double cnt = (double)HW * gs;
       const double md = da / cnt;
       double var = db / cnt - md * md;
@@ -687,7 +687,8 @@ extern "C" int crg_groupnorm_pre(crg_ctx* ctx, void* stream, const void* x, cons
   // ... while a sample's partials stay small next to the block's own share of the tensor (80 KB: 16 tiles x 640 channels; a 128 x 128 level
   // has 64 tiles per sample - 490 KB in front of every block of a 960-channel concat - and keeps the finalise launch)
   const long fold_floats = (long)(HW / rows1) * C1 + (x2 ? (long)(HW / rows2) * (C - C1) : 0);
-  const bool fold_in_apply = rows1 >= 64 && (!x2 || rows2 >= 64) && C <= GN_TILE_MAX_C && fold_floats <= 10240;
+  const bool fold_in_apply = rows1 >= 64 && (!x2 || rows2 >= 64) && C <= GN_TILE_MAX_C && fold_floats <= 10240 &&
+                             (((uintptr_t)stats1 | (uintptr_t)stats2) & 15) == 0;  // (16-byte loads of the partial rows)
   float* mr = nullptr;
   if (!fold_in_apply) {
     mr = (float*)crg_scratch(ctx, (size_t)N * groups * 2 * sizeof(float));
