@@ -151,6 +151,8 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise CrgError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(cremage_amd has no CPU or PyTorch fallback)")
+    import torch  # noqa: F401  (before the dlopen: the library must resolve the HIP runtime to the one PyTorch loads; with the system
+    #                             runtime loaded first the process ends up with two, and the one behind this library sees no device)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
