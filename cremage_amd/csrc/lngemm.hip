@@ -159,10 +159,9 @@ static __device__ __forceinline__ void ln_wait_nw(int nW) {
   else ln_wait(nW + EXTRA);
 }
 
-// ALIAS: the weight ring lies OVER the resident rows (they are only needed until every wave holds its activation fragments in
-// registers), which makes room for 256-column n-tiles (four 32 KB slots = 128 KB): half the barriers and a third fewer fragment
-// reads per FLOP.  K-tile u then lives in slot (u + 3) & 3, so that k-tile 0 can land (slot 3, beyond the rows) during the prologue.
-template <int WNT, int KT, bool GEGLU, bool ALIAS = false>
+// (Round 3's ALIAS form of this kernel - the GEGLU ring laid over the resident rows for 256-column n-tiles - went when
+//  lngemm_geglu_pp_kernel below, which keeps that layout, replaced it in round 4: 82 -> 77.6 us at 32768 x 2560 x 320.)
+template <int WNT, int KT, bool GEGLU>
 __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
   constexpr bool PAIR = !GEGLU;  // plain outputs use the paired column mapping (16-byte stores); GEGLU its own [v16 | g16] packing
   constexpr int WMT = 2, NW = 8, BMR = 128, WST = 4;
@@ -176,9 +175,7 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
   constexpr int OOB = (int)0x80000000;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Ares = smem;                  // [KT][128][128 B], chunk XOR-swizzled by (row & 7)
-  char* const wring = ALIAS ? smem : smem + KT * A_KT;  // [WST][BN x 128 B]
-  static_assert(!ALIAS || 3 * WS_BYTES >= KT * A_KT, "slot 3 must lie beyond the resident rows");
-  constexpr int SROT = ALIAS ? 3 : 0;       // k-tile u -> ring slot (u + SROT) & 3
+  char* const wring = smem + KT * A_KT;     // [WST][BN x 128 B]
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -212,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
   }
   auto stage_w = [&](int u) {  // weight k-tile u = (n-tile u / KT, k-tile u % KT) into ring slot u & 3
     const int nt = u / KT, kt = u - nt * KT;
-    char* ws = wring + ((u + SROT) & 3) * WS_BYTES;
+    char* ws = wring + (u & 3) * WS_BYTES;
     const int soff = (int)((long)nt * BN * p.ldw * 2) + kt * 128;  // rows past N fall beyond w_bytes: zero-filled
 #pragma unroll
     for (int q = 0; q < WL; ++q)
@@ -221,10 +218,8 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
   // (weight k-tiles past the last one: their rows lie beyond w_bytes, the DMA writes zeros into slots nobody reads - issuing them
   // anyway keeps every wait of the loop at its steady-state count and every fragment read unconditional)
   stage_w(0);
-  if (!ALIAS) {
-    stage_w(1);
-    stage_w(2);
-  }
+  stage_w(1);
+  stage_w(2);
 
   // ---- LayerNorm of the resident rows, in place: wave w owns rows 16 w .. 16 w + 15, 8 lanes per row ----
   // (gamma == null: no LayerNorm - the kernel is then a plain row-resident GEMM for K = 320)
@@ -241,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
     }
     // the rows (older than the three weight batches) have landed once at most 3 nW operations of this wave are outstanding;
     // the gamma / beta loads above are younger still, the compiler waits for them itself at their first use
-    ln_wait(nW * (ALIAS ? 1 : 3));
+    ln_wait(nW * 3);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -314,31 +309,7 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
 #pragma unroll
       for (int j = 0; j < WMT; ++j) acc[i][j] = CRG_MFMA_16x16x32(wf[i], xf[j], acc[i][j]);
   };
-  if constexpr (ALIAS) {
-    // rows landed (no LayerNorm: nobody waited yet), normalised rows published -> fragments into registers -> the rows' LDS becomes
-    // ring slots 0 .. 2: only now may k-tiles 1 and 2 be requested
-    ln_wait(nW);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int j = 0; j < WMT; ++j) xa[kt][ks][j] = *reinterpret_cast<const bf16x8*>(Ares + kt * A_KT + (aoff[j] ^ (ks << 6)));
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the fragments are in registers
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    stage_w(1);
-    stage_w(2);
-    ln_wait(nW * 2);  // k-tile 0 (requested first) landed
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    read_frags(wf0, SROT, 0);
-  } else {
+  {
     // weight k-tile 0 landed (two batches may stay in flight); this barrier also publishes the normalised rows
     ln_wait(nW * 2);
     asm volatile("" ::: "memory");
@@ -378,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
       // (ablation builds -DCRG_LN_ABL_NOMMA / -DCRG_LN_ABL_NODMA, N = 2560 GEGLU: 87 us full, 82 without the DMA, 66 without the
       // MFMAs, 53 without either: barrier + fragment reads + prologue / epilogue are the larger part.  Running the two waves of a
       // SIMD in opposite orders - w + 4 issues its first MFMA block before its fragment reads - measured 88 -> 91 us, not kept.)
-      read_frags(wf1, (u + SROT) & 3, 1);
+      read_frags(wf1, u & 3, 1);
       __builtin_amdgcn_sched_barrier(0);
 #ifndef CRG_LN_ABL_NOMMA
       mma(xa[kt][0], wf0);
@@ -389,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void lngemm_kernel(LnGemmP p) {
 #endif
       // unconditional (after the last k-tile it reads a slot of zeros): behind a branch the compiler cannot count these reads and
       // makes the MFMAs below wait for lgkmcnt(0), i.e. for the prefetch as well as for their own operands
-      read_frags(wf0, (u + 1 + SROT) & 3, 0);
+      read_frags(wf0, (u + 1) & 3, 0);
       __builtin_amdgcn_sched_barrier(0);
 #ifndef CRG_LN_ABL_NOMMA
       mma(xa[kt][1], wf1);
@@ -808,10 +779,8 @@ extern "C" int crg_ln_gemm(crg_ctx* ctx, void* stream, const crg_lngemm_args* a)
   hipStream_t st = (hipStream_t)stream;
   void (*kern)(LnGemmP);
   int bn;
-  static const int use_alias = getenv("CRG_LN_WIDE") ? atoi(getenv("CRG_LN_WIDE")) : 1;  // dev knob: 0 = 128-column GEGLU tiles
-  const bool alias = geglu && use_alias && a->N % 256 == 0;
-  static const int use_pp = getenv("CRG_LN_PP") ? atoi(getenv("CRG_LN_PP")) : 1;  // dev knob: 0 = lockstep GEGLU kernel
-  if (alias && use_pp && a->N <= 8192) {
+  static const int use_pp = getenv("CRG_LN_PP") ? atoi(getenv("CRG_LN_PP")) : 1;  // dev knob: 0 = lockstep 128-column GEGLU tiles
+  if (geglu && use_pp && a->N % 256 == 0 && a->N <= 8192) {  // two wave groups in opposite phases (bias in LDS: N <= 8192)
     kern = lngemm_geglu_pp_kernel<5>;
     const size_t lds_pp = (size_t)8 * 128 * 128 + (size_t)a->N * 4;
     if (int rc = crg_set_dyn_lds(ctx, reinterpret_cast<const void*>(kern), 160 * 1024, "ln_gemm")) return rc;
@@ -822,11 +791,10 @@ extern "C" int crg_ln_gemm(crg_ctx* ctx, void* stream, const crg_lngemm_args* a)
     CRG_CHECK_LAUNCH(ctx, "ln_gemm");
     return 0;
   }
-  if (alias) { kern = lngemm_kernel<8, 5, true, true>; bn = 256; }
-  else if (geglu) { kern = lngemm_kernel<4, 5, true>; bn = 128; }
+  if (geglu) { kern = lngemm_kernel<4, 5, true>; bn = 128; }
   else if (wide) { kern = lngemm_kernel<5, 5, false>; bn = 160; }
   else { kern = lngemm_kernel<4, 5, false>; bn = 128; }
-  const size_t lds = alias ? (size_t)4 * bn * 128 : (size_t)5 * 128 * 128 + (size_t)4 * bn * 128;
+  const size_t lds = (size_t)5 * 128 * 128 + (size_t)4 * bn * 128;
   if (int rc = crg_set_dyn_lds(ctx, reinterpret_cast<const void*>(kern), 160 * 1024, "ln_gemm")) return rc;
   const double flops = 2.0 * a->M * (double)a->N * a->K;
   const double bytes = (double)a->M * a->K * 2 + (double)a->N * a->K * 2 + (double)a->M * n_out * 2;

@@ -223,7 +223,7 @@ def test_geglu(dtype, M, C):
                                           (1000, 2560, "geglu", False)])
 def test_ln_linear(M, N, act, bias):
     """crg_ln_gemm (LayerNorm fused into the consuming GEMM, K = 320; lngemm.hip) against LayerNorm -> bf16 rounding -> Linear:
-    row tails (M % 128 != 0), 160- and 128-wide tiles, the 256-wide GEGLU tiles whose weight ring overlays the resident rows
+    row tails (M % 128 != 0), 160- and 128-wide tiles, the anti-phase GEGLU kernel whose weight ring overlays the resident rows
     (N % 256 == 0), the paired and the plain column mapping, bias, GEGLU, and bitwise
     agreement of the normalised operand with the stand-alone crg_layernorm (same two-pass arithmetic)."""
     from cremage_amd import ops
